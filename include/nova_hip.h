@@ -1,0 +1,247 @@
+/*
+ * nova_hip.h — C ABI of the MI355X (gfx950) ray-tracing backend for Nova.
+ *
+ * This is the drop-in boundary: everything Nova's `src/backend` abstraction needs from a device
+ * backend (buffers, images, the three kernel launches), as plain C entry points with plain
+ * pointers and sizes.  The C++ header-only wrappers in nova_amd/backend/hip/ (the code a
+ * `-DBACKEND=HIP` build of Nova compiles in place of src/backend/cuda/) call only these
+ * functions.  Every entry point cites the reference interface it replaces; paths are relative
+ * to the Nova source tree.
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a hipError_t value (>0) or one of the
+ *     NOVA_HIP_E_* codes (<0); nothing throws across this boundary;
+ *   - calls are synchronous like the reference's (`cudaDeviceSynchronize()` after every launch,
+ *     src/backend/cuda/accelerator/accelerator.hpp:26-29), single host thread per device;
+ *   - device pointers handed to the launchers must come from nova_hip_malloc (the library keeps
+ *     a ptr -> size registry so that the launchers know how many nodes/triangles a buffer holds:
+ *     the reference's kernels receive bare pointers, kernels/kernels.cu:13-16).
+ */
+#ifndef NOVA_HIP_H
+#define NOVA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * POD layouts: the headers of src/kernel_types/ as a HIP (or CUDA) host compiler lays them out, i.e. a
+ * 3-vector is 12 bytes, float2 is 8-byte aligned, float4 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { float x, y; } __attribute__((aligned(8))) nova_float2;
+typedef struct { float x, y, z; } nova_float3;
+typedef struct { float x, y, z, w; } __attribute__((aligned(16))) nova_float4;
+typedef struct { uint8_t x, y, z, w; } __attribute__((aligned(4))) nova_uchar4;
+
+/* src/kernel_types/bvh_node.hpp:13-16 */
+typedef struct {
+  nova_float4 top_offset_left;  /* xyz = box max; w = first triangle (leaf) */
+  nova_float4 bottom_num_right; /* xyz = box min; w = right child (>= 0) or -count (leaf) */
+} nova_bvh_node;                /* 32 bytes */
+
+/* src/kernel_types/triangle.hpp:10-12 — rows of the Woop world->unit-triangle affine map */
+typedef struct { nova_float4 x, y, z; } nova_triangle_data; /* 48 bytes */
+
+/* src/kernel_types/triangle.hpp:14-35 */
+typedef struct {
+  nova_float3 normal1, normal2, normal3;
+  nova_float3 tangent1, tangent2, tangent3;
+  nova_float3 bitangent1, bitangent2, bitangent3;
+  nova_float2 texture_coord1, texture_coord2, texture_coord3;
+  nova_float3 kD;
+  float metallic;
+  float roughness;
+  int32_t diffuse_index;
+  int32_t metallic_index;
+  int32_t roughness_index;
+  int32_t normal_index;
+  int32_t light_index;
+} nova_triangle_meta; /* 176 bytes */
+
+/* src/kernel_types/area_light.hpp:8-32 */
+enum { NOVA_LIGHT_RECT = 0, NOVA_LIGHT_TRI = 1 };
+typedef struct {
+  nova_float3 intensity;
+  union {
+    struct { nova_float3 position, normal, dims; } rect;
+    struct { nova_float3 v1, v2, v3; } tri;
+  };
+  uint8_t type; /* AreaLightType : bool */
+} nova_area_light; /* 52 bytes */
+
+/* src/kernel_types/eye_coords.hpp:9-14 and matrix.hpp:8-12 */
+typedef struct { nova_float3 x, y, z; } nova_mat3x3;
+typedef struct {
+  nova_float2 coord_scale;
+  nova_float2 coord_dims;
+  nova_float3 eye_pos;
+  nova_mat3x3 eye_coord_frame;
+} nova_eye_coords; /* 64 bytes */
+
+/* src/kernel_types/scene_params.hpp:9-18 */
+typedef struct {
+  nova_eye_coords eye_coords;
+  nova_float3 shading_diffuse;
+  float shading_metallic;
+  float shading_roughness;
+  char path_tracing;
+  int32_t num_samples;
+  float exposure;
+  char anti_aliasing;
+} nova_scene_params; /* 104 bytes */
+
+/* ---------------------------------------------------------------------------------------------
+ * Errors.  Replaces nova::Error / get_error_string (src/backend/cuda/types/error.hpp:10-17).
+ * ------------------------------------------------------------------------------------------- */
+enum {
+  NOVA_HIP_OK = 0,
+  NOVA_HIP_E_INVALID_ARGUMENT = -1, /* null/zero-sized/ill-formed argument */
+  NOVA_HIP_E_UNKNOWN_BUFFER = -2,   /* device pointer not allocated by nova_hip_malloc */
+  NOVA_HIP_E_BAD_SCENE = -3,        /* BVH does not parse (child index out of range, ...) */
+  NOVA_HIP_E_NO_DEVICE = -4,        /* no HIP device / device ordinal out of range */
+  NOVA_HIP_E_TOO_LARGE = -5         /* request exceeds a documented maximum */
+};
+const char* nova_hip_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device.  The reference picks its device in the Accelerator constructor
+ * (src/backend/opencl/accelerator/accelerator.cpp:11-25; CUDA: implicit device 0).
+ * nova_hip_init selects the device for the calling process and creates the library's per-device
+ * context (stream, work queues).  It is idempotent.
+ * ------------------------------------------------------------------------------------------- */
+int nova_hip_init(int device_ordinal);
+int nova_hip_device_count(int* count);
+int nova_hip_device_name(char* out, size_t out_bytes);
+int nova_hip_synchronize(void);
+int nova_hip_shutdown(void); /* frees every cached scene and work buffer of the current device */
+
+/* ---------------------------------------------------------------------------------------------
+ * Buffers.  Replace nova::Buffer<T> (src/backend/cuda/types/buffer.hpp:11-86): constructor
+ * (cudaMalloc [+ upload]) -> nova_hip_malloc [+ nova_hip_memcpy_h2d]; destructor -> nova_hip_free;
+ * write -> memcpy_h2d; read -> memcpy_d2h; fill -> nova_hip_fill.
+ * ------------------------------------------------------------------------------------------- */
+int nova_hip_malloc(void** dev_ptr, size_t bytes);
+int nova_hip_free(void* dev_ptr);
+int nova_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int nova_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int nova_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);
+/* dst[i] = *pattern for i in [0, count); pattern_bytes in {1, 2, 4, 8, 16} */
+int nova_hip_fill(void* dst_dev, const void* pattern, size_t pattern_bytes, size_t count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Images.  CDNA has no image/sampler hardware, so an image is a linear row-major HBM buffer
+ * plus the sampler state the reference attaches at creation.  Replace Image2DRead/Write/
+ * ReadWrite/Array (src/backend/cuda/types/image2D*.hpp) and Accelerator::create_image2D_*,
+ * read_image2D, write_image2D, copy_image2D, fill_image2D
+ * (src/backend/cuda/accelerator/accelerator.hpp:32-177).
+ * Sampling semantics follow the reference's OpenCL path (kernels/backend/opencl/image.hpp:14-21):
+ * float coordinates = normalised, LINEAR filter; CLAMP = border colour 0; WRAP = REPEAT.
+ * ------------------------------------------------------------------------------------------- */
+enum { NOVA_ADDRESS_WRAP = 0, NOVA_ADDRESS_CLAMP = 1 };
+enum { NOVA_FILTER_NEAREST = 0, NOVA_FILTER_LINEAR = 1 };
+typedef struct nova_hip_image {
+  void* data;          /* device pointer, width*height*layers*texel_bytes bytes */
+  uint32_t width;
+  uint32_t height;
+  uint32_t layers;     /* 1 for a plain 2D image */
+  uint32_t texel_bytes;/* 16 = float4, 4 = uchar4 */
+  uint32_t address_mode;
+  uint32_t filter_mode;
+  uint32_t normalized_coords;
+} nova_hip_image;
+
+/* `host_data` may be NULL (uninitialised image). */
+int nova_hip_image_create(nova_hip_image** image, uint32_t texel_bytes, uint32_t width,
+                          uint32_t height, uint32_t layers, uint32_t address_mode,
+                          uint32_t filter_mode, uint32_t normalized_coords,
+                          const void* host_data);
+int nova_hip_image_destroy(nova_hip_image* image);
+int nova_hip_image_read(const nova_hip_image* image, void* host_dst);
+int nova_hip_image_write(nova_hip_image* image, const void* host_src);
+int nova_hip_image_copy(nova_hip_image* dst, const nova_hip_image* src);
+int nova_hip_image_fill(nova_hip_image* image, const void* texel);
+
+/* ---------------------------------------------------------------------------------------------
+ * The three kernels.  Argument lists are those of kernels/kernels.cu:9-22, :42-53, :94-97
+ * (= kernels/entrypoint/cuda/entrypoint.hpp:12-49 without the launch geometry: the reference's
+ * 8x4 work-groups would idle half of every wave64, so geometry is the backend's business).
+ * Buffers are the device pointers of the reference's layouts above; the BVH is repacked into the
+ * backend's own 64-byte node layout on first use and cached until a buffer is freed or rewritten.
+ * `albedo_feature*`/`normal_feature*` may be NULL when denoise_available == 0 and `lights` may be
+ * NULL when num_lights == 0 (src/core/raytracer.cpp:81-100, :129-132).
+ * ------------------------------------------------------------------------------------------- */
+int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time,
+                             nova_hip_image* temp_color1, uint32_t width, uint32_t height,
+                             const nova_triangle_data* triangles,
+                             const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                             const nova_area_light* lights, uint32_t num_lights,
+                             const nova_hip_image* materials, const nova_hip_image* sky,
+                             uint32_t denoise_available, nova_hip_image* albedo_feature1,
+                             nova_hip_image* normal_feature1);
+
+int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
+                               const nova_hip_image* temp_color1,
+                               const nova_hip_image* albedo_feature1,
+                               const nova_hip_image* normal_feature1,
+                               const nova_hip_image* prev_color,
+                               const nova_hip_image* prev_albedo_feature,
+                               const nova_hip_image* prev_normal_feature,
+                               nova_hip_image* temp_color2, nova_hip_image* albedo_feature2,
+                               nova_hip_image* normal_feature2, uint32_t width, uint32_t height);
+
+int nova_hip_launch_post_process(const nova_scene_params* params,
+                                 const nova_hip_image* temp_color2, nova_hip_image* pixels,
+                                 uint32_t width, uint32_t height);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray batches.  find_intersection (kernels/raytrace.hpp:38-102) over an array of rays, for
+ * callers that generate their own rays (BASELINE config 4: 16 M incoherent rays per batch).
+ * Each ray is built as the reference builds it at every call site (raytrace.hpp:132,216,239):
+ * Ray(point, direction, RAY_EPSILON).  rays_point_tmax[i] = {point.xyz, tmax} (tmax = FLT_MAX for
+ * an unbounded ray), rays_dir_flags[i] = {direction.xyz, as_float(flags)}, flags bit 0 = any-hit.
+ * hits[i] = {t, barycentric.y, barycentric.z, as_float(int triangle index or -1)}.
+ * All three arrays are device pointers from nova_hip_malloc.
+ * ------------------------------------------------------------------------------------------- */
+int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
+                        const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
+                        nova_float4* hits, uint64_t num_rays);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backend options and counters (no counterpart in the reference, which has neither a bounce
+ * cap, a fixed seed nor ray counters; SURVEY.md §7 "Hard parts").  Options are per process.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+  NOVA_HIP_OPT_MAX_DEPTH = 1,   /* max path segments per sample; 0 = unbounded (reference) */
+  NOVA_HIP_OPT_TRAVERSAL = 2,   /* 0 = ordered + distance-culled (default);
+                                   1 = reference walk: fixed order, no culling (validation) */
+  NOVA_HIP_OPT_COUNT_WORK = 3,  /* 1 = also count node visits / triangle tests (slower) */
+  NOVA_HIP_OPT_TILE_RANK = 4,   /* image-tile partition for multi-GPU: this process renders the */
+  NOVA_HIP_OPT_TILE_RANKS = 5,  /* tiles with (tile_id % ranks) == rank; tiles are 64x64 pixels; */
+                                /* pixels of other tiles are left untouched by kernel_raytrace */
+  NOVA_HIP_OPT_TRAVERSE_KERNEL = 6 /* internal A/B switch between traversal kernel variants */
+};
+int nova_hip_set_option(int option, int64_t value);
+int nova_hip_get_option(int option, int64_t* value);
+
+typedef struct {
+  uint64_t rays_primary;      /* find_intersection calls for first path segments */
+  uint64_t rays_bounce;       /* closest-hit calls for later segments and MIS rays */
+  uint64_t rays_shadow;       /* any-hit calls */
+  uint64_t node_visits;       /* box-pair nodes fetched (NOVA_HIP_OPT_COUNT_WORK) */
+  uint64_t triangle_tests;    /* intersects_triangle evaluations (NOVA_HIP_OPT_COUNT_WORK) */
+  uint64_t path_segments;     /* shaded hits */
+  double traverse_ms;         /* device time of traversal kernels since the last reset */
+  double shade_ms;            /* device time of generate/shade kernels since the last reset */
+  uint64_t traverse_launches;
+} nova_hip_counters;
+int nova_hip_get_counters(nova_hip_counters* out);
+int nova_hip_reset_counters(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NOVA_HIP_H */
