@@ -1,0 +1,286 @@
+"""ctypes binding of the C ABI in ``include/nova_hip.h`` (``libnova_hip.so``).
+
+This is plumbing only: every call goes straight to the HIP library.  There is no CPU fallback —
+if the library is missing, or the box has no HIP device, calls raise ``NovaHipError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnova_hip.so")
+
+# option ids (include/nova_hip.h)
+OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT_TRAVERSE_KERNEL = \
+    1, 2, 3, 4, 5, 6
+ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+
+EXPORTS = [
+    "nova_hip_error_string", "nova_hip_init", "nova_hip_device_count", "nova_hip_device_name",
+    "nova_hip_synchronize", "nova_hip_shutdown", "nova_hip_malloc", "nova_hip_free",
+    "nova_hip_memcpy_h2d", "nova_hip_memcpy_d2h", "nova_hip_memcpy_d2d", "nova_hip_fill",
+    "nova_hip_image_create", "nova_hip_image_destroy", "nova_hip_image_read",
+    "nova_hip_image_write", "nova_hip_image_copy", "nova_hip_image_fill",
+    "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
+    "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
+    "nova_hip_reset_counters",
+]
+
+
+class NovaHipError(RuntimeError):
+    """Mirrors nova::Error (src/backend/cuda/types/error.hpp:10-17): carries the error code."""
+
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what} (code {code})")
+        self.code = code
+
+    def err(self) -> int:
+        return self.code
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("rays_primary", ctypes.c_uint64), ("rays_bounce", ctypes.c_uint64),
+                ("rays_shadow", ctypes.c_uint64), ("node_visits", ctypes.c_uint64),
+                ("triangle_tests", ctypes.c_uint64), ("path_segments", ctypes.c_uint64),
+                ("traverse_ms", ctypes.c_double), ("shade_ms", ctypes.c_double),
+                ("traverse_launches", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class ImageDesc(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("layers", ctypes.c_uint32), ("texel_bytes", ctypes.c_uint32),
+                ("address_mode", ctypes.c_uint32), ("filter_mode", ctypes.c_uint32),
+                ("normalized_coords", ctypes.c_uint32)]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NovaHipError(-4, f"{LIB_PATH} is missing; build it with __graft_entry__.build()")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u32, u64, i32, i64, sz = (ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32,
+                                  ctypes.c_int64, ctypes.c_size_t)
+    lib.nova_hip_error_string.restype = ctypes.c_char_p
+    lib.nova_hip_error_string.argtypes = [ctypes.c_int]
+    sig = {
+        "nova_hip_init": [ctypes.c_int],
+        "nova_hip_device_count": [vp],
+        "nova_hip_device_name": [ctypes.c_char_p, sz],
+        "nova_hip_synchronize": [],
+        "nova_hip_shutdown": [],
+        "nova_hip_malloc": [vp, sz],
+        "nova_hip_free": [vp],
+        "nova_hip_memcpy_h2d": [vp, vp, sz],
+        "nova_hip_memcpy_d2h": [vp, vp, sz],
+        "nova_hip_memcpy_d2d": [vp, vp, sz],
+        "nova_hip_fill": [vp, vp, sz, sz],
+        "nova_hip_image_create": [vp, u32, u32, u32, u32, u32, u32, u32, vp],
+        "nova_hip_image_destroy": [vp],
+        "nova_hip_image_read": [vp, vp],
+        "nova_hip_image_write": [vp, vp],
+        "nova_hip_image_copy": [vp, vp],
+        "nova_hip_image_fill": [vp, vp],
+        "nova_hip_launch_raytrace": [vp, u32, vp, u32, u32, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp],
+        "nova_hip_launch_accumulate": [i32, u32] + [vp] * 9 + [u32, u32],
+        "nova_hip_launch_post_process": [vp, vp, vp, u32, u32],
+        "nova_hip_trace_rays": [vp, vp, vp, vp, vp, u64],
+        "nova_hip_set_option": [ctypes.c_int, i64],
+        "nova_hip_get_option": [ctypes.c_int, vp],
+        "nova_hip_get_counters": [vp],
+        "nova_hip_reset_counters": [],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int):
+    if code != 0:
+        raise NovaHipError(code, load().nova_hip_error_string(code).decode())
+
+
+def init(device: int = 0):
+    check(load().nova_hip_init(device))
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    check(load().nova_hip_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name() -> str:
+    buf = ctypes.create_string_buffer(256)
+    check(load().nova_hip_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def set_option(opt: int, value: int):
+    check(load().nova_hip_set_option(opt, value))
+
+
+def get_option(opt: int) -> int:
+    v = ctypes.c_int64(0)
+    check(load().nova_hip_get_option(opt, ctypes.byref(v)))
+    return v.value
+
+
+def counters() -> dict:
+    c = Counters()
+    check(load().nova_hip_get_counters(ctypes.byref(c)))
+    return c.as_dict()
+
+
+def reset_counters():
+    check(load().nova_hip_reset_counters())
+
+
+def synchronize():
+    check(load().nova_hip_synchronize())
+
+
+class Buffer:
+    """nova::Buffer<T> (src/backend/cuda/types/buffer.hpp:11-86) over nova_hip_malloc."""
+
+    def __init__(self, data: Optional[np.ndarray] = None, nbytes: Optional[int] = None):
+        lib = load()
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            nbytes = data.nbytes
+        if not nbytes:
+            raise ValueError("Cannot build an empty Buffer")  # AcceleratorException in the reference
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(lib.nova_hip_malloc(ctypes.byref(p), self.nbytes))
+        self.ptr = p.value
+        if data is not None:
+            self.write(data)
+
+    def write(self, data: np.ndarray):
+        data = np.ascontiguousarray(data)
+        assert data.nbytes <= self.nbytes
+        check(load().nova_hip_memcpy_h2d(self.ptr, data.ctypes.data, data.nbytes))
+
+    def read(self, dtype, count: Optional[int] = None) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        n = self.nbytes // dtype.itemsize if count is None else count
+        out = np.empty(n, dtype)
+        check(load().nova_hip_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            check(load().nova_hip_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Image:
+    """Image2DRead/Write/ReadWrite/Array (src/backend/cuda/types/image2D*.hpp) as a linear buffer."""
+
+    def __init__(self, width: int, height: int, layers: int = 1, texel_bytes: int = 16,
+                 address_mode: int = ADDRESS_CLAMP, filter_mode: int = FILTER_LINEAR,
+                 normalized: bool = True, data: Optional[np.ndarray] = None):
+        if width == 0 or height == 0 or layers == 0:
+            raise ValueError("Cannot build an empty Image2D")
+        self.width, self.height, self.layers, self.texel_bytes = width, height, layers, texel_bytes
+        h = ctypes.c_void_p()
+        src = None
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            assert data.nbytes == width * height * layers * texel_bytes, (data.shape, width, height)
+            src = data.ctypes.data
+        check(load().nova_hip_image_create(ctypes.byref(h), texel_bytes, width, height, layers,
+                                           address_mode, filter_mode, 1 if normalized else 0, src))
+        self.handle = h.value
+
+    def read(self) -> np.ndarray:
+        if self.texel_bytes == 16:
+            out = np.empty((self.layers, self.height, self.width, 4), np.float32)
+        else:
+            out = np.empty((self.layers, self.height, self.width, 4), np.uint8)
+        check(load().nova_hip_image_read(self.handle, out.ctypes.data))
+        return out[0] if self.layers == 1 else out
+
+    def write(self, data: np.ndarray):
+        data = np.ascontiguousarray(data)
+        assert data.nbytes == self.width * self.height * self.layers * self.texel_bytes
+        check(load().nova_hip_image_write(self.handle, data.ctypes.data))
+
+    def copy_from(self, src: "Image"):
+        check(load().nova_hip_image_copy(self.handle, src.handle))
+
+    def fill(self, texel):
+        t = np.ascontiguousarray(texel, np.float32 if self.texel_bytes == 16 else np.uint8)
+        assert t.nbytes == self.texel_bytes
+        check(load().nova_hip_image_fill(self.handle, t.ctypes.data))
+
+    @property
+    def data_ptr(self) -> int:
+        return ImageDesc.from_address(self.handle).data
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            check(load().nova_hip_image_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _h(img: Optional[Image]):
+    return None if img is None else img.handle
+
+
+def launch_raytrace(params: np.ndarray, time: int, temp_color1: Image, width: int, height: int,
+                    triangles: Buffer, tri_meta: Buffer, bvh: Buffer, lights: Optional[Buffer],
+                    num_lights: int, materials: Image, sky: Image, denoise_available: int,
+                    albedo1: Optional[Image], normal1: Optional[Image]):
+    params = np.ascontiguousarray(params)
+    check(load().nova_hip_launch_raytrace(
+        params.ctypes.data, time & 0xFFFFFFFF, _h(temp_color1), width, height, triangles.ptr,
+        tri_meta.ptr, bvh.ptr, None if lights is None else lights.ptr, num_lights, _h(materials),
+        _h(sky), denoise_available, _h(albedo1), _h(normal1)))
+
+
+def launch_accumulate(sample_index: int, denoise_available: int, color1, albedo1, normal1,
+                      prev_color, prev_albedo, prev_normal, color2, albedo2, normal2, width, height):
+    check(load().nova_hip_launch_accumulate(
+        sample_index, denoise_available, _h(color1), _h(albedo1), _h(normal1), _h(prev_color),
+        _h(prev_albedo), _h(prev_normal), _h(color2), _h(albedo2), _h(normal2), width, height))
+
+
+def launch_post_process(params: np.ndarray, color2: Image, pixels: Image, width: int, height: int):
+    params = np.ascontiguousarray(params)
+    check(load().nova_hip_launch_post_process(params.ctypes.data, _h(color2), _h(pixels), width,
+                                              height))
+
+
+def trace_rays(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Buffer, hits: Buffer,
+               num_rays: int):
+    check(load().nova_hip_trace_rays(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
+                                     hits.ptr, num_rays))

@@ -1,0 +1,840 @@
+// libnova_hip.so — host side of the C ABI declared in include/nova_hip.h: per-process device
+// context, buffer registry, linear images, BVH repack + scene cache, and the launch schedules of
+// the wavefront pipeline (generate -> traverse -> shade ... ) and the streaming image kernels.
+// gfx950 only.  No PyTorch, no CUDA shims, no CPU fallback: without a HIP device every entry
+// point fails with NOVA_HIP_E_NO_DEVICE / the hipError_t.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "image_kernels.hpp"
+#include "nova_hip.h"
+#include "shade.hpp"
+#include "traverse.hpp"
+
+using namespace nova_hip;
+
+static_assert(sizeof(nova_bvh_node) == 32, "FlatBVHNode layout");
+static_assert(sizeof(nova_triangle_data) == 48, "TriangleData layout");
+static_assert(sizeof(nova_triangle_meta) == 176, "TriangleMetaData layout");
+static_assert(sizeof(nova_area_light) == 52, "AreaLightData layout");
+static_assert(sizeof(nova_eye_coords) == 64, "EyeCoords layout");
+static_assert(sizeof(nova_scene_params) == 104, "SceneParams layout");
+static_assert(offsetof(nova_triangle_meta, texture_coord1) == 112, "TriangleMetaData layout");
+static_assert(offsetof(nova_scene_params, path_tracing) == 84, "SceneParams layout");
+static_assert(sizeof(Node64) == 64, "Node64 layout");
+
+namespace {
+
+constexpr uint32_t kMaxIterations = 1024; // hard cap on path length in unbounded mode
+constexpr uint32_t kTileSize = 64;
+
+#define HIP_TRY(expr)                        \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) return static_cast<int>(e_); \
+  } while (0)
+
+struct Alloc {
+  size_t bytes;
+  uint64_t version;
+};
+
+struct PackedScene {
+  const void* bvh_ptr = nullptr;
+  const void* tri_ptr = nullptr;
+  uint64_t bvh_version = 0, tri_version = 0;
+  Node64* nodes = nullptr;
+  uint32_t n_packed = 0;
+  uint32_t n_tris = 0;
+  uint32_t stack_need = 0;
+  float root_top[3], root_bot[3];
+};
+
+struct FrameBuffers {
+  uint32_t capacity = 0; // paths
+  float4* planes[2][6] = {};
+  float4* ray_o[2] = {};
+  float4* ray_d[2] = {};
+  float4* hits = nullptr;
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  std::unordered_map<const void*, Alloc> allocs;
+  uint64_t next_version = 1;
+  std::vector<PackedScene> scenes;
+  FrameBuffers fb;
+  uint32_t* d_queues = nullptr;          // [0..kMaxIterations+1] n_active, then queue heads
+  unsigned long long* d_counters = nullptr; // 8 x u64
+  uint32_t* h_pinned = nullptr;          // readback word
+  // options
+  int64_t opt_max_depth = 0, opt_traversal = 0, opt_count_work = 0, opt_tile_rank = 0,
+          opt_tile_ranks = 1, opt_kernel = 0;
+  // timing
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_traverse, ev_shade;
+  double traverse_ms = 0, shade_ms = 0;
+  uint64_t traverse_launches = 0;
+};
+
+Ctx g;
+std::mutex g_mutex;
+
+int require_ctx() {
+  if (!g.ready) {
+    int rc = nova_hip_init(0);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+const Alloc* find_alloc(const void* p) {
+  auto it = g.allocs.find(p);
+  return it == g.allocs.end() ? nullptr : &it->second;
+}
+
+void drop_scenes_using(const void* p) {
+  for (size_t i = 0; i < g.scenes.size();) {
+    if (g.scenes[i].bvh_ptr == p || g.scenes[i].tri_ptr == p) {
+      (void) hipFree(g.scenes[i].nodes);
+      g.scenes.erase(g.scenes.begin() + i);
+    } else {
+      i++;
+    }
+  }
+}
+
+void touch(const void* p) {
+  auto it = g.allocs.find(p);
+  if (it != g.allocs.end()) it->second.version = g.next_version++;
+}
+
+hipEvent_t next_event() {
+  if (g.ev_used == g.ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g.ev_pool.push_back(e);
+  }
+  return g.ev_pool[g.ev_used++];
+}
+
+void collect_events() {
+  for (auto& p : g.ev_traverse) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) g.traverse_ms += ms;
+  }
+  for (auto& p : g.ev_shade) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) g.shade_ms += ms;
+  }
+  g.ev_traverse.clear();
+  g.ev_shade.clear();
+  g.ev_used = 0;
+}
+
+// ---- BVH repack: FlatBVHNode[] (DFS pre-order, left child adjacent; src/bvh/bvh.cpp:211-249)
+// -> dense array of 64-byte box-pair nodes.
+struct Packer {
+  const std::vector<nova_bvh_node>& in;
+  uint32_t n_tris;
+  std::vector<Node64> out;
+  uint32_t max_depth = 0;
+  bool bad = false;
+
+  static bool is_leaf(const nova_bvh_node& n) { return !(n.bottom_num_right.w >= 0.0f); }
+
+  static void set_child(Node64& nd, int k, const nova_float4& top, const nova_float4& bot, uint32_t ref) {
+    if (k == 0) {
+      nd.a = make_float4(top.x, top.y, top.z, __builtin_bit_cast(float, ref));
+      nd.b.x = bot.x; nd.b.y = bot.y; nd.b.z = bot.z;
+    } else {
+      nd.c = make_float4(top.x, top.y, top.z, 0.0f);
+      nd.d = make_float4(bot.x, bot.y, bot.z, 0.0f);
+      nd.b.w = __builtin_bit_cast(float, ref);
+    }
+  }
+  static void set_empty_child(Node64& nd, int k) {
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    nova_float4 v = { qnan, qnan, qnan, 0.0f };
+    set_child(nd, k, v, v, kLeafBit); // never entered: a NaN box fails `tmin <= tmax`
+  }
+
+  // reference of the subtree rooted at original node i (depth = number of packed levels above)
+  uint32_t ref_of(uint32_t i, uint32_t depth) {
+    if (bad) return kLeafBit;
+    const nova_bvh_node& n = in[i];
+    if (is_leaf(n)) {
+      const float foff = n.top_offset_left.w, fcnt = -n.bottom_num_right.w;
+      if (!(foff >= 0.0f) || !(fcnt >= 1.0f) || foff >= 16777216.0f || fcnt > 16777216.0f) { bad = true; return kLeafBit; }
+      const uint32_t off = static_cast<uint32_t>(foff), cnt = static_cast<uint32_t>(fcnt);
+      if (static_cast<uint64_t>(off) + cnt > n_tris) { bad = true; return kLeafBit; }
+      max_depth = std::max(max_depth, depth);
+      if (cnt <= kMaxLeafTris) return kLeafBit | ((cnt - 1u) << 24) | off;
+      // oversized leaf: chain of box-pair nodes, each holding one chunk and the rest
+      return chain(n, off, cnt, depth);
+    }
+    const float fr = n.bottom_num_right.w;
+    const uint32_t right = static_cast<uint32_t>(fr);
+    if (static_cast<float>(right) != fr || right <= i + 1 || right >= in.size() || i + 1 >= in.size() ||
+        out.size() >= in.size() + 16 || depth > 1100) {
+      bad = true;
+      return kLeafBit;
+    }
+    const uint32_t slot = static_cast<uint32_t>(out.size());
+    out.emplace_back();
+    const uint32_t r0 = ref_of(i + 1, depth + 1);
+    const uint32_t r1 = ref_of(right, depth + 1);
+    set_child(out[slot], 0, in[i + 1].top_offset_left, in[i + 1].bottom_num_right, r0);
+    set_child(out[slot], 1, in[right].top_offset_left, in[right].bottom_num_right, r1);
+    return slot;
+  }
+
+  uint32_t chain(const nova_bvh_node& leaf, uint32_t off, uint32_t cnt, uint32_t depth) {
+    const uint32_t slot = static_cast<uint32_t>(out.size());
+    out.emplace_back();
+    const uint32_t head = kLeafBit | ((kMaxLeafTris - 1u) << 24) | off;
+    const uint32_t rest = cnt - kMaxLeafTris;
+    uint32_t r1;
+    if (rest <= kMaxLeafTris) {
+      r1 = kLeafBit | ((rest - 1u) << 24) | (off + kMaxLeafTris);
+      max_depth = std::max(max_depth, depth + 1);
+    } else {
+      r1 = chain(leaf, off + kMaxLeafTris, rest, depth + 1);
+    }
+    set_child(out[slot], 0, leaf.top_offset_left, leaf.bottom_num_right, head);
+    set_child(out[slot], 1, leaf.top_offset_left, leaf.bottom_num_right, r1);
+    return slot;
+  }
+};
+
+int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedScene** out) {
+  const Alloc* ab = find_alloc(bvh);
+  const Alloc* at = find_alloc(tris);
+  if (!ab || !at) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  for (auto& s : g.scenes) {
+    if (s.bvh_ptr == bvh && s.tri_ptr == tris && s.bvh_version == ab->version && s.tri_version == at->version) {
+      *out = &s;
+      return 0;
+    }
+  }
+  drop_scenes_using(bvh); // stale entries for a rewritten buffer
+  const size_t n_nodes = ab->bytes / sizeof(nova_bvh_node);
+  const size_t n_tris = at->bytes / sizeof(nova_triangle_data);
+  if (n_nodes == 0 || n_tris == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (n_tris > (1u << 24)) return NOVA_HIP_E_TOO_LARGE;
+  std::vector<nova_bvh_node> host(n_nodes);
+  HIP_TRY(hipMemcpy(host.data(), bvh, n_nodes * sizeof(nova_bvh_node), hipMemcpyDeviceToHost));
+
+  Packer pk { host, static_cast<uint32_t>(n_tris) };
+  pk.out.reserve(n_nodes / 2 + 2);
+  const nova_bvh_node& root = host[0];
+  if (Packer::is_leaf(root)) {
+    // a single-leaf tree: give it a parent whose second child is never entered
+    pk.out.emplace_back();
+    const uint32_t r0 = pk.ref_of(0, 1);
+    // ref_of may have appended chain nodes; out[0] stays the synthetic root
+    Packer::set_child(pk.out[0], 0, root.top_offset_left, root.bottom_num_right, r0);
+    Packer::set_empty_child(pk.out[0], 1);
+  } else {
+    pk.ref_of(0, 0);
+  }
+  if (pk.bad || pk.out.empty()) return NOVA_HIP_E_BAD_SCENE;
+  if (pk.max_depth > 64) return NOVA_HIP_E_TOO_LARGE; // the reference's own STACK_SIZE (kernels/constants.hpp:8)
+
+  PackedScene s;
+  s.bvh_ptr = bvh;
+  s.tri_ptr = tris;
+  s.bvh_version = ab->version;
+  s.tri_version = at->version;
+  s.n_packed = static_cast<uint32_t>(pk.out.size());
+  s.n_tris = static_cast<uint32_t>(n_tris);
+  s.stack_need = pk.max_depth;
+  s.root_top[0] = root.top_offset_left.x; s.root_top[1] = root.top_offset_left.y; s.root_top[2] = root.top_offset_left.z;
+  s.root_bot[0] = root.bottom_num_right.x; s.root_bot[1] = root.bottom_num_right.y; s.root_bot[2] = root.bottom_num_right.z;
+  HIP_TRY(hipMalloc(&s.nodes, pk.out.size() * sizeof(Node64)));
+  hipError_t e = hipMemcpy(s.nodes, pk.out.data(), pk.out.size() * sizeof(Node64), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void) hipFree(s.nodes);
+    return static_cast<int>(e);
+  }
+  g.scenes.push_back(s);
+  *out = &g.scenes.back();
+  return 0;
+}
+
+template <int STACK>
+int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
+  const int blocks_per_cu = STACK <= 32 ? 4 : 2;
+  dim3 grid(static_cast<unsigned>(g.num_cus * blocks_per_cu)), block(256);
+  if (cull) {
+    if (count) hipLaunchKernelGGL((k_traverse<STACK, true, true>), grid, block, 0, g.stream, A);
+    else hipLaunchKernelGGL((k_traverse<STACK, true, false>), grid, block, 0, g.stream, A);
+  } else {
+    if (count) hipLaunchKernelGGL((k_traverse<STACK, false, true>), grid, block, 0, g.stream, A);
+    else hipLaunchKernelGGL((k_traverse<STACK, false, false>), grid, block, 0, g.stream, A);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_traverse(const PackedScene& s, TraverseArgs A) {
+  A.nodes = s.nodes;
+  A.tris = reinterpret_cast<const float4*>(s.tri_ptr);
+  std::memcpy(A.root_top, s.root_top, sizeof(A.root_top));
+  std::memcpy(A.root_bot, s.root_bot, sizeof(A.root_bot));
+  A.work_counters = g.d_counters;
+  const bool cull = g.opt_traversal == 0, count = g.opt_count_work != 0;
+  hipEvent_t e0 = next_event(), e1 = next_event();
+  if (e0) (void) hipEventRecord(e0, g.stream);
+  int rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
+  if (e1) (void) hipEventRecord(e1, g.stream);
+  if (e0 && e1) g.ev_traverse.push_back({ e0, e1 });
+  g.traverse_launches++;
+  return rc;
+}
+
+int ensure_frame_buffers(uint32_t paths) {
+  FrameBuffers& fb = g.fb;
+  if (fb.capacity >= paths) return 0;
+  auto release = [&]() {
+    for (int s = 0; s < 2; s++) {
+      for (int k = 0; k < 6; k++) { (void) hipFree(fb.planes[s][k]); fb.planes[s][k] = nullptr; }
+      (void) hipFree(fb.ray_o[s]); fb.ray_o[s] = nullptr;
+      (void) hipFree(fb.ray_d[s]); fb.ray_d[s] = nullptr;
+    }
+    (void) hipFree(fb.hits); fb.hits = nullptr;
+    fb.capacity = 0;
+  };
+  release();
+  const size_t plane = static_cast<size_t>(paths) * sizeof(float4);
+  for (int s = 0; s < 2; s++) {
+    for (int k = 0; k < 6; k++) {
+      hipError_t e = hipMalloc(&fb.planes[s][k], plane);
+      if (e != hipSuccess) { release(); return static_cast<int>(e); }
+    }
+    hipError_t e = hipMalloc(&fb.ray_o[s], 3 * plane);
+    if (e == hipSuccess) e = hipMalloc(&fb.ray_d[s], 3 * plane);
+    if (e != hipSuccess) { release(); return static_cast<int>(e); }
+  }
+  hipError_t e = hipMalloc(&fb.hits, 3 * plane);
+  if (e != hipSuccess) { release(); return static_cast<int>(e); }
+  fb.capacity = paths;
+  return 0;
+}
+
+PathPlanes planes_of(int side) {
+  FrameBuffers& fb = g.fb;
+  return { fb.planes[side][0], fb.planes[side][1], fb.planes[side][2],
+           fb.planes[side][3], fb.planes[side][4], fb.planes[side][5] };
+}
+
+bool float_image_ok(const nova_hip_image* im, uint32_t w, uint32_t h) {
+  return im && im->data && im->texel_bytes == 16 && im->width == w && im->height == h && im->layers >= 1;
+}
+
+}
+
+extern "C" {
+
+const char* nova_hip_error_string(int code) {
+  switch (code) {
+    case NOVA_HIP_OK: return "success";
+    case NOVA_HIP_E_INVALID_ARGUMENT: return "nova_hip: invalid argument";
+    case NOVA_HIP_E_UNKNOWN_BUFFER: return "nova_hip: device pointer was not allocated by nova_hip_malloc";
+    case NOVA_HIP_E_BAD_SCENE: return "nova_hip: malformed BVH";
+    case NOVA_HIP_E_NO_DEVICE: return "nova_hip: no usable HIP device";
+    case NOVA_HIP_E_TOO_LARGE: return "nova_hip: request exceeds a documented maximum";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+  return "nova_hip: unknown error";
+}
+
+int nova_hip_device_count(int* count) {
+  if (!count) return NOVA_HIP_E_INVALID_ARGUMENT;
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e == hipErrorNoDevice) { *count = 0; return 0; }
+  return static_cast<int>(e);
+}
+
+int nova_hip_init(int device_ordinal) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (g.ready && g.device == device_ordinal) return 0;
+  if (g.ready) return NOVA_HIP_E_INVALID_ARGUMENT; // one device per process
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NOVA_HIP_E_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= n) return NOVA_HIP_E_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+  g.num_cus = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(&g.d_queues, 2 * (kMaxIterations + 2) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&g.d_counters, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc(&g.h_pinned, 64, hipHostMallocDefault));
+  g.device = device_ordinal;
+  g.ready = true;
+  return 0;
+}
+
+int nova_hip_device_name(char* out, size_t out_bytes) {
+  if (!out || out_bytes == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+  std::snprintf(out, out_bytes, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+int nova_hip_synchronize(void) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  return 0;
+}
+
+int nova_hip_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  if (!g.ready) return 0;
+  (void) hipStreamSynchronize(g.stream);
+  collect_events();
+  for (auto& s : g.scenes) (void) hipFree(s.nodes);
+  g.scenes.clear();
+  for (int s = 0; s < 2; s++) {
+    for (int k = 0; k < 6; k++) { (void) hipFree(g.fb.planes[s][k]); g.fb.planes[s][k] = nullptr; }
+    (void) hipFree(g.fb.ray_o[s]); g.fb.ray_o[s] = nullptr;
+    (void) hipFree(g.fb.ray_d[s]); g.fb.ray_d[s] = nullptr;
+  }
+  (void) hipFree(g.fb.hits);
+  g.fb.hits = nullptr;
+  g.fb.capacity = 0;
+  return 0;
+}
+
+// ---- buffers -----------------------------------------------------------------------------------
+int nova_hip_malloc(void** dev_ptr, size_t bytes) {
+  if (!dev_ptr || bytes == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  g.allocs[p] = { bytes, g.next_version++ };
+  *dev_ptr = p;
+  return 0;
+}
+
+int nova_hip_free(void* dev_ptr) {
+  if (!dev_ptr) return 0;
+  auto it = g.allocs.find(dev_ptr);
+  if (it == g.allocs.end()) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  drop_scenes_using(dev_ptr);
+  g.allocs.erase(it);
+  HIP_TRY(hipFree(dev_ptr));
+  return 0;
+}
+
+int nova_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
+  if (!dst_dev || !src_host) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  touch(dst_dev);
+  return 0;
+}
+
+int nova_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
+  if (!dst_host || !src_dev) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nova_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes) {
+  if (!dst_dev || !src_dev) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
+  touch(dst_dev);
+  return 0;
+}
+
+int nova_hip_fill(void* dst_dev, const void* pattern, size_t pattern_bytes, size_t count) {
+  if (!dst_dev || !pattern) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  int rc = require_ctx();
+  if (rc) return rc;
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((count + 255) / 256, 4096));
+  switch (pattern_bytes) {
+    case 1: { uint8_t v; std::memcpy(&v, pattern, 1);
+      hipLaunchKernelGGL(k_fill<uint8_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint8_t*>(dst_dev), v, count); break; }
+    case 2: { uint16_t v; std::memcpy(&v, pattern, 2);
+      hipLaunchKernelGGL(k_fill<uint16_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint16_t*>(dst_dev), v, count); break; }
+    case 4: { uint32_t v; std::memcpy(&v, pattern, 4);
+      hipLaunchKernelGGL(k_fill<uint32_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint32_t*>(dst_dev), v, count); break; }
+    case 8: { uint2 v; std::memcpy(&v, pattern, 8);
+      hipLaunchKernelGGL(k_fill<uint2>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint2*>(dst_dev), v, count); break; }
+    case 16: { uint4 v; std::memcpy(&v, pattern, 16);
+      hipLaunchKernelGGL(k_fill<uint4>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint4*>(dst_dev), v, count); break; }
+    default: return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  touch(dst_dev);
+  return 0;
+}
+
+// ---- images ------------------------------------------------------------------------------------
+int nova_hip_image_create(nova_hip_image** image, uint32_t texel_bytes, uint32_t width, uint32_t height,
+                          uint32_t layers, uint32_t address_mode, uint32_t filter_mode,
+                          uint32_t normalized_coords, const void* host_data) {
+  if (!image || width == 0 || height == 0 || layers == 0 || (texel_bytes != 16 && texel_bytes != 4))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  const size_t bytes = static_cast<size_t>(width) * height * layers * texel_bytes;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  if (host_data) {
+    hipError_t e = hipMemcpy(p, host_data, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void) hipFree(p); return static_cast<int>(e); }
+  }
+  nova_hip_image* im = new nova_hip_image { p, width, height, layers, texel_bytes, address_mode, filter_mode, normalized_coords };
+  *image = im;
+  return 0;
+}
+
+int nova_hip_image_destroy(nova_hip_image* image) {
+  if (!image) return 0;
+  hipError_t e = hipFree(image->data);
+  delete image;
+  return static_cast<int>(e);
+}
+
+static size_t image_bytes(const nova_hip_image* im) {
+  return static_cast<size_t>(im->width) * im->height * im->layers * im->texel_bytes;
+}
+
+int nova_hip_image_read(const nova_hip_image* image, void* host_dst) {
+  if (!image || !image->data || !host_dst) return NOVA_HIP_E_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpy(host_dst, image->data, image_bytes(image), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nova_hip_image_write(nova_hip_image* image, const void* host_src) {
+  if (!image || !image->data || !host_src) return NOVA_HIP_E_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpy(image->data, host_src, image_bytes(image), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int nova_hip_image_copy(nova_hip_image* dst, const nova_hip_image* src) {
+  if (!dst || !src || !dst->data || !src->data || image_bytes(dst) != image_bytes(src))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpy(dst->data, src->data, image_bytes(dst), hipMemcpyDeviceToDevice));
+  return 0;
+}
+
+int nova_hip_image_fill(nova_hip_image* image, const void* texel) {
+  if (!image || !image->data || !texel) return NOVA_HIP_E_INVALID_ARGUMENT;
+  return nova_hip_fill(image->data, texel, image->texel_bytes,
+                       static_cast<size_t>(image->width) * image->height * image->layers);
+}
+
+// ---- options / counters ------------------------------------------------------------------------
+int nova_hip_set_option(int option, int64_t value) {
+  switch (option) {
+    case NOVA_HIP_OPT_MAX_DEPTH:
+      if (value < 0 || value >= kMaxIterations) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_max_depth = value; return 0;
+    case NOVA_HIP_OPT_TRAVERSAL:
+      if (value != 0 && value != 1) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_traversal = value; return 0;
+    case NOVA_HIP_OPT_COUNT_WORK: g.opt_count_work = value != 0; return 0;
+    case NOVA_HIP_OPT_TILE_RANK:
+      if (value < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_tile_rank = value; return 0;
+    case NOVA_HIP_OPT_TILE_RANKS:
+      if (value < 1) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_tile_ranks = value; return 0;
+    case NOVA_HIP_OPT_TRAVERSE_KERNEL: g.opt_kernel = value; return 0;
+    default: return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+}
+
+int nova_hip_get_option(int option, int64_t* value) {
+  if (!value) return NOVA_HIP_E_INVALID_ARGUMENT;
+  switch (option) {
+    case NOVA_HIP_OPT_MAX_DEPTH: *value = g.opt_max_depth; return 0;
+    case NOVA_HIP_OPT_TRAVERSAL: *value = g.opt_traversal; return 0;
+    case NOVA_HIP_OPT_COUNT_WORK: *value = g.opt_count_work; return 0;
+    case NOVA_HIP_OPT_TILE_RANK: *value = g.opt_tile_rank; return 0;
+    case NOVA_HIP_OPT_TILE_RANKS: *value = g.opt_tile_ranks; return 0;
+    case NOVA_HIP_OPT_TRAVERSE_KERNEL: *value = g.opt_kernel; return 0;
+    default: return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+}
+
+int nova_hip_get_counters(nova_hip_counters* out) {
+  if (!out) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpy(h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  out->node_visits = h[0];
+  out->triangle_tests = h[1];
+  out->rays_primary = h[2];
+  out->rays_bounce = h[3];
+  out->rays_shadow = h[4];
+  out->path_segments = h[5];
+  out->traverse_ms = g.traverse_ms;
+  out->shade_ms = g.shade_ms;
+  out->traverse_launches = g.traverse_launches;
+  return 0;
+}
+
+int nova_hip_reset_counters(void) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+  g.traverse_ms = g.shade_ms = 0;
+  g.traverse_launches = 0;
+  return 0;
+}
+
+// ---- kernel_raytrace ---------------------------------------------------------------------------
+int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nova_hip_image* temp_color1,
+                             uint32_t width, uint32_t height, const nova_triangle_data* triangles,
+                             const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                             const nova_area_light* lights, uint32_t num_lights,
+                             const nova_hip_image* materials, const nova_hip_image* sky,
+                             uint32_t denoise_available, nova_hip_image* albedo_feature1,
+                             nova_hip_image* normal_feature1) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!params || !triangles || !tri_meta || !bvh || width == 0 || height == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!float_image_ok(temp_color1, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (denoise_available && (!float_image_ok(albedo_feature1, width, height) || !float_image_ok(normal_feature1, width, height)))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!materials || !materials->data || materials->texel_bytes != 16 || !sky || !sky->data || sky->texel_bytes != 16)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (num_lights > 0 && !lights) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const Alloc* am = find_alloc(tri_meta);
+  if (!am) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  if (num_lights > 0) {
+    const Alloc* al = find_alloc(lights);
+    if (!al) return NOVA_HIP_E_UNKNOWN_BUFFER;
+    if (al->bytes < static_cast<size_t>(num_lights) * sizeof(nova_area_light)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+  PackedScene* scene = nullptr;
+  rc = get_scene(bvh, triangles, &scene);
+  if (rc) return rc;
+  if (am->bytes < static_cast<size_t>(scene->n_tris) * sizeof(nova_triangle_meta)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (g.opt_tile_rank >= g.opt_tile_ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
+
+  const uint32_t tiles_x = (width + kTileSize - 1) / kTileSize, tiles_y = (height + kTileSize - 1) / kTileSize;
+  const uint32_t n_tiles = tiles_x * tiles_y;
+  const uint32_t rank = static_cast<uint32_t>(g.opt_tile_rank), ranks = static_cast<uint32_t>(g.opt_tile_ranks);
+  const uint32_t n_my_tiles = n_tiles > rank ? (n_tiles - rank + ranks - 1) / ranks : 0;
+  if (n_my_tiles == 0) return 0;
+  if (static_cast<uint64_t>(n_my_tiles) * 4096ull * 3ull >= (1ull << 31)) return NOVA_HIP_E_TOO_LARGE;
+  const uint32_t P = n_my_tiles * 4096u;
+  rc = ensure_frame_buffers(P);
+  if (rc) return rc;
+
+  FrameArgs F;
+  std::memset(&F, 0, sizeof(F));
+  F.params = *params;
+  F.time = time;
+  F.width = width;
+  F.height = height;
+  F.tile_rank = rank;
+  F.tile_ranks = ranks;
+  F.tiles_x = tiles_x;
+  F.n_my_tiles = n_my_tiles;
+  F.meta = tri_meta;
+  F.lights = lights;
+  F.num_lights = num_lights;
+  F.materials = { static_cast<const float4*>(materials->data), static_cast<int>(materials->width),
+                  static_cast<int>(materials->height), static_cast<int>(materials->layers) };
+  F.sky = { static_cast<const float4*>(sky->data), static_cast<int>(sky->width), static_cast<int>(sky->height), 1 };
+  F.denoise = denoise_available ? 1u : 0u;
+  F.out_color = static_cast<float4*>(temp_color1->data);
+  F.out_albedo = denoise_available ? static_cast<float4*>(albedo_feature1->data) : nullptr;
+  F.out_normal = denoise_available ? static_cast<float4*>(normal_feature1->data) : nullptr;
+  F.stride = P;
+  F.max_depth = static_cast<uint32_t>(g.opt_max_depth);
+  F.n_active = g.d_queues;
+  F.counters = g.d_counters;
+  uint32_t* queue_heads = g.d_queues + (kMaxIterations + 2);
+
+  HIP_TRY(hipMemsetAsync(g.d_queues, 0, 2 * (kMaxIterations + 2) * sizeof(uint32_t), g.stream));
+  const unsigned blocks = (P + 255) / 256;
+  {
+    hipEvent_t e0 = next_event(), e1 = next_event();
+    if (e0) (void) hipEventRecord(e0, g.stream);
+    hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, g.stream, F, planes_of(0), g.fb.ray_o[0], g.fb.ray_d[0]);
+    if (e1) (void) hipEventRecord(e1, g.stream);
+    if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
+  }
+  HIP_TRY(hipGetLastError());
+
+  const bool path_tracing = params->path_tracing != 0;
+  const bool nee = path_tracing && num_lights > 0;
+  uint32_t last_it;
+  if (!path_tracing) last_it = 0;
+  else if (F.max_depth != 0) last_it = nee ? F.max_depth : F.max_depth - 1;
+  else last_it = kMaxIterations - 1;
+
+  for (uint32_t it = 0; it <= last_it; it++) {
+    const int in = it & 1, out = in ^ 1;
+    TraverseArgs T;
+    std::memset(&T, 0, sizeof(T));
+    T.ray_o = g.fb.ray_o[in];
+    T.ray_d = g.fb.ray_d[in];
+    T.hits = g.fb.hits;
+    T.n_items_ptr = g.d_queues + it;
+    T.kinds = (nee && it > 0) ? 3u : 1u;
+    T.stride = P;
+    T.queue_head = queue_heads + it;
+    rc = launch_traverse(*scene, T);
+    if (rc) return rc;
+    {
+      hipEvent_t e0 = next_event(), e1 = next_event();
+      if (e0) (void) hipEventRecord(e0, g.stream);
+      hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, g.stream, F, it, planes_of(in), planes_of(out),
+                         g.fb.ray_o[in], g.fb.ray_d[in], g.fb.hits, g.fb.ray_o[out], g.fb.ray_d[out]);
+      if (e1) (void) hipEventRecord(e1, g.stream);
+      if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
+    }
+    HIP_TRY(hipGetLastError());
+    // unbounded mode: poll the survivor count now and then (paths die by miss / Russian roulette)
+    if (F.max_depth == 0 && path_tracing && it >= 3 && (it & 1u)) {
+      HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_queues + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+      HIP_TRY(hipStreamSynchronize(g.stream));
+      if (*g.h_pinned == 0) break;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  return 0;
+}
+
+// ---- kernel_accumulate -------------------------------------------------------------------------
+int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
+                               const nova_hip_image* temp_color1, const nova_hip_image* albedo_feature1,
+                               const nova_hip_image* normal_feature1, const nova_hip_image* prev_color,
+                               const nova_hip_image* prev_albedo_feature,
+                               const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
+                               nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
+                               uint32_t width, uint32_t height) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (width == 0 || height == 0 || sample_index < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!float_image_ok(temp_color1, width, height) || !float_image_ok(temp_color2, width, height) ||
+      !float_image_ok(prev_color, width, height))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (denoise_available) {
+    const nova_hip_image* need[] = { albedo_feature1, normal_feature1, prev_albedo_feature,
+                                     prev_normal_feature, albedo_feature2, normal_feature2 };
+    for (const nova_hip_image* im : need)
+      if (!float_image_ok(im, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+  AccumulateArgs A;
+  A.sample_index = sample_index;
+  A.denoise = denoise_available ? 1u : 0u;
+  auto ptr = [](const nova_hip_image* im) { return im ? static_cast<float4*>(im->data) : nullptr; };
+  A.color1 = ptr(temp_color1);
+  A.albedo1 = ptr(albedo_feature1);
+  A.normal1 = ptr(normal_feature1);
+  A.prev_color = ptr(prev_color);
+  A.prev_albedo = ptr(prev_albedo_feature);
+  A.prev_normal = ptr(prev_normal_feature);
+  A.color2 = ptr(temp_color2);
+  A.albedo2 = ptr(albedo_feature2);
+  A.normal2 = ptr(normal_feature2);
+  A.n_pixels = width * height;
+  const unsigned blocks = std::min<unsigned>((A.n_pixels + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+  hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, g.stream, A);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+// ---- kernel_post_process -----------------------------------------------------------------------
+int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip_image* temp_color2,
+                                 nova_hip_image* pixels, uint32_t width, uint32_t height) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!params || width == 0 || height == 0 || !float_image_ok(temp_color2, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!pixels || !pixels->data || pixels->texel_bytes != 4 || pixels->width != width || pixels->height != height)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  PostArgs A;
+  A.color2 = { static_cast<const float4*>(temp_color2->data), static_cast<int>(width), static_cast<int>(height), 1 };
+  A.pixels = static_cast<uchar4*>(pixels->data);
+  A.width = width;
+  A.height = height;
+  A.exposure = params->exposure;
+  A.anti_aliasing = params->anti_aliasing ? 1u : 0u;
+  const unsigned n = width * height;
+  const unsigned blocks = std::min<unsigned>((n + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+  hipLaunchKernelGGL(k_post_process, dim3(blocks), dim3(256), 0, g.stream, A);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+// ---- ray batches -------------------------------------------------------------------------------
+int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
+                        const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
+                        nova_float4* hits, uint64_t num_rays) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!triangles || !bvh || !rays_point_tmax || !rays_dir_flags || !hits) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (num_rays == 0) return 0;
+  if (num_rays >= (1ull << 31)) return NOVA_HIP_E_TOO_LARGE;
+  const Alloc* a0 = find_alloc(rays_point_tmax);
+  const Alloc* a1 = find_alloc(rays_dir_flags);
+  const Alloc* a2 = find_alloc(hits);
+  if (!a0 || !a1 || !a2) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  if (a0->bytes < num_rays * 16 || a1->bytes < num_rays * 16 || a2->bytes < num_rays * 16)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  PackedScene* scene = nullptr;
+  rc = get_scene(bvh, triangles, &scene);
+  if (rc) return rc;
+  uint32_t* queue_heads = g.d_queues + (kMaxIterations + 2);
+  HIP_TRY(hipMemsetAsync(queue_heads, 0, sizeof(uint32_t), g.stream));
+  TraverseArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.ray_o = reinterpret_cast<const float4*>(rays_point_tmax);
+  T.ray_d = reinterpret_cast<const float4*>(rays_dir_flags);
+  T.hits = reinterpret_cast<float4*>(hits);
+  T.n_items_ptr = nullptr;
+  T.n_items_imm = static_cast<uint32_t>(num_rays);
+  T.kinds = 1;
+  T.stride = 0;
+  T.queue_head = queue_heads;
+  rc = launch_traverse(*scene, T);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  touch(hits);
+  return 0;
+}
+
+}

@@ -1,0 +1,202 @@
+// BVH traversal + Woop ray/triangle intersection for gfx950: the replacement for
+// find_intersection / intersects_aabb / intersects_triangle
+// (reference kernels/raytrace.hpp:38-102, kernels/intersection.hpp:14-52).
+//
+// Layout (built by repack_bvh in nova_hip.hip from the reference's FlatBVHNode[]):
+//   * one 64-byte, 64-byte-aligned Node64 per INNER node holding BOTH children's boxes, so one
+//     cache line fetched per step yields two slab tests (the reference fetches a 32-byte node per
+//     box test, dependent on the previous one);
+//   * child reference: bit 31 = leaf; leaf: bits 24-30 = triangle count - 1, bits 0-23 = first
+//     triangle (the reference stores indices as floats, so they are < 2^24 anyway); inner: index
+//     of the child's Node64.  Inner nodes are renumbered densely in DFS order;
+//   * triangles stay as the reference's 48-byte Woop matrices in leaf order.
+//
+// Execution: persistent work-groups pull 64-ray batches from a global queue head (one atomic
+// per wave per batch); one ray per lane; the traversal stack lives in LDS as [entry][lane]
+// (bank = lane mod 32: conflict-free for ds_read/write_b32), never in scratch memory.
+//
+// Semantics: the boxes tested are exactly the reference's (same operations, same order of
+// operands), so the set of triangles reachable is the reference's.  Closest hit = min t over
+// reachable triangles, ties -> lowest triangle index (the reference visits triangles in
+// increasing index order with a strict `t < length`).  CULL=true visits the nearer child first and
+// skips subtrees wholly behind the origin or beyond the current hit, with a safety margin
+// (kCull*) far above the rounding of the slab and Woop arithmetic; CULL=false is the
+// reference's own walk (fixed order, no culling) and is kept as the validation mode.
+#pragma once
+
+#include "device_math.hpp"
+
+namespace nova_hip {
+
+struct __attribute__((aligned(64))) Node64 {
+  float4 a; // child0 box max.xyz, w = child0 reference (bits)
+  float4 b; // child0 box min.xyz, w = child1 reference (bits)
+  float4 c; // child1 box max.xyz, w = unused
+  float4 d; // child1 box min.xyz, w = unused
+};
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kMaxLeafTris = 128;
+constexpr float kCullRel = 1e-4f;    // relative slack on the current hit distance
+constexpr float kCullAbs = 1e-4f;    // absolute slack on the current hit distance
+constexpr float kCullBehind = -1e-3f; // a box is "behind" only if it ends before this t
+
+struct TraverseArgs {
+  const Node64* nodes;
+  const float4* tris; // 3 x float4 per triangle
+  float root_top[3];
+  float root_bot[3];
+  const float4* ray_o;      // {point.xyz, tmax}; tmax < 0 marks an empty slot
+  const float4* ray_d;      // {direction.xyz, flags}; bit 0 = any-hit
+  float4* hits;             // {t, u, v, triangle index}
+  const uint32_t* n_items_ptr; // number of active items, read on the device (or null)
+  uint32_t n_items_imm;
+  uint32_t kinds;  // work items = n_items * kinds; item w -> slot (w / n) * stride + (w % n)
+  uint32_t stride;
+  uint32_t* queue_head;
+  unsigned long long* work_counters; // [0] node fetches, [1] triangle tests (COUNT only)
+};
+
+struct RayState {
+  V3 o, d, inv, nio;
+};
+
+NV_DEV bool slab(const RayState& r, float4 top, float4 bot, float& tmin, float& tmax) {
+  float t1x = fma_(top.x, r.inv.x, r.nio.x), t1y = fma_(top.y, r.inv.y, r.nio.y), t1z = fma_(top.z, r.inv.z, r.nio.z);
+  float t2x = fma_(bot.x, r.inv.x, r.nio.x), t2y = fma_(bot.y, r.inv.y, r.nio.y), t2z = fma_(bot.z, r.inv.z, r.nio.z);
+  tmin = max_(min_(t1x, t2x), max_(min_(t1y, t2y), min_(t1z, t2z)));
+  tmax = min_(max_(t1x, t2x), min_(max_(t1y, t2y), max_(t1z, t2z)));
+  return tmin <= tmax;
+}
+
+struct HitState {
+  float t, u, v;
+  int id;
+};
+
+// kernels/intersection.hpp:14-37.  Returns true when the hit was accepted.
+NV_DEV bool woop(const RayState& r, HitState& h, int index, float4 mx, float4 my, float4 mz) {
+  float oz = fma_(mz.x, r.o.x, fma_(mz.y, r.o.y, fma_(mz.z, r.o.z, mz.w)));
+  float dz = fma_(mz.x, r.d.x, fma_(mz.y, r.d.y, mz.z * r.d.z));
+  float t = -oz / dz;
+  if (t < 0.0f || !__builtin_isfinite(t)) return false;
+  if (t >= h.t) {
+    if (!(t == h.t && h.id >= 0 && index < h.id)) return false;
+  }
+  float ox = fma_(mx.x, r.o.x, fma_(mx.y, r.o.y, fma_(mx.z, r.o.z, mx.w)));
+  float oy = fma_(my.x, r.o.x, fma_(my.y, r.o.y, fma_(my.z, r.o.z, my.w)));
+  float dx = fma_(mx.x, r.d.x, fma_(mx.y, r.d.y, mx.z * r.d.z));
+  float dy = fma_(my.x, r.d.x, fma_(my.y, r.d.y, my.z * r.d.z));
+  float u = fma_(t, dx, ox);
+  float v = fma_(t, dy, oy);
+  float w = (1.0f - u) - v;
+  if (w < 0.0f || u < 0.0f || v < 0.0f) return false;
+  h.t = t;
+  h.u = u;
+  h.v = v;
+  h.id = index;
+  return true;
+}
+
+template <int STACK, bool CULL, bool COUNT>
+__device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)[64], uint32_t lane,
+                                          float4 o4, float4 d4, HitState& h, uint32_t& n_nodes,
+                                          uint32_t& n_tris) {
+  RayState r;
+  r.d = xyz(d4);
+  r.o = fma3(r.d, kRayEpsilon, xyz(o4)); // kernels/types.hpp:16-20
+  r.inv = { 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };
+  r.nio = (-r.o) * r.inv;
+  const bool anyhit = (__float_as_uint(d4.w) & 1u) != 0;
+
+  float tmin, tmax;
+  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
+  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
+  if (!slab(r, rt, rb, tmin, tmax)) return;
+
+  float far_limit = fma_(h.t, kCullRel, h.t) + kCullAbs;
+  uint32_t sp = 0;
+  uint32_t cur = 0;
+  while (true) {
+    if (!(cur & kLeafBit)) {
+      const Node64* nd = A.nodes + cur;
+      const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
+      if (COUNT) n_nodes++;
+      float tmin0, tmax0, tmin1, tmax1;
+      bool h0 = slab(r, na, nb, tmin0, tmax0);
+      bool h1 = slab(r, nc, ndd, tmin1, tmax1);
+      if (CULL) {
+        h0 = h0 && (tmax0 >= kCullBehind) && (tmin0 <= far_limit);
+        h1 = h1 && (tmax1 >= kCullBehind) && (tmin1 <= far_limit);
+      }
+      const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
+      if (h0 && h1) {
+        const bool swap = CULL && (tmin1 < tmin0);
+        stk[sp++][lane] = swap ? ref0 : ref1;
+        cur = swap ? ref1 : ref0;
+        continue;
+      }
+      if (h0) { cur = ref0; continue; }
+      if (h1) { cur = ref1; continue; }
+    } else {
+      const uint32_t first = cur & 0x00FFFFFFu;
+      const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
+      bool done = false;
+      for (uint32_t i = first; i < first + count; i++) {
+        const float4* m = A.tris + 3 * static_cast<size_t>(i);
+        if (COUNT) n_tris++;
+        if (woop(r, h, static_cast<int>(i), m[0], m[1], m[2])) {
+          if (anyhit) { done = true; break; }
+          far_limit = fma_(h.t, kCullRel, h.t) + kCullAbs;
+        }
+      }
+      if (done) return;
+    }
+    if (sp == 0) return;
+    cur = stk[--sp][lane];
+  }
+}
+
+template <int STACK, bool CULL, bool COUNT>
+__global__ __launch_bounds__(256) void k_traverse(TraverseArgs A) {
+  __shared__ uint32_t lds_stack[4][STACK][64];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t (*stk)[64] = lds_stack[threadIdx.x >> 6];
+  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
+  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  uint32_t n_nodes = 0, n_tris = 0;
+
+  while (true) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(A.queue_head, 64u);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= total) break;
+    const uint32_t w = base + lane;
+    if (w < total) {
+      const uint32_t kind = w / n;
+      const uint32_t j = w - kind * n;
+      const size_t slot = static_cast<size_t>(kind) * A.stride + j;
+      const float4 o4 = A.ray_o[slot];
+      const float4 d4 = A.ray_d[slot];
+      HitState h { o4.w, 0.0f, 0.0f, -1 };
+      if (!(o4.w < 0.0f)) {
+        trace_one<STACK, CULL, COUNT>(A, stk, lane, o4, d4, h, n_nodes, n_tris);
+      }
+      A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+    }
+  }
+  if (COUNT) {
+    // one atomic per wave per counter
+    unsigned long long a = n_nodes, b = n_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.work_counters[0], a);
+      atomicAdd(&A.work_counters[1], b);
+    }
+  }
+}
+
+}

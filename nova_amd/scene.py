@@ -501,3 +501,29 @@ def decode_ids(color: np.ndarray) -> np.ndarray:
     ids = c[:, 0].astype(np.int64) + (c[:, 1].astype(np.int64) << 12)
     ids[c[:, 2] != 1.0] = -1
     return ids.astype(np.int32)
+
+
+def cornell_box() -> Scene:
+    """BASELINE config 1 scene, from the committed data fixture tests/golden/cornell_box.npz
+    (generated from the reference's public-domain Cornell box OBJ by make_cornell_fixture.py)."""
+    path = os.path.join(_HERE, "..", "tests", "golden", "cornell_box.npz")
+    z = np.load(path)
+    meta = np.ascontiguousarray(z["meta"]).view(TRIANGLE_META).reshape(-1)
+    return build_scene(z["verts"], meta, z["emissive"])
+
+
+CORNELL_CAMERA = dict(position=[0.0, 0.0, 5.0], target=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0], fovy=30.0)
+DRAGON_CAMERA = dict(position=[-1.7, 1.1, -0.8], target=[0.0, -0.1, 0.0], up=[0.0, 1.0, 0.0], fovy=45.0)
+
+
+def dragon_standin(nu=660, nv=660) -> Scene:
+    """BASELINE config 2 stand-in (assets/dragon/dragon.glb is absent): the displaced torus knot
+    with the light and ground plane of scene.toml's dragon section (scene.toml:47-74)."""
+    verts = knot_mesh(nu, nv)
+    light = np.zeros(1, RECT_LIGHT)
+    light["intensity"], light["position"] = (500.0, 500.0, 500.0), (-1.4, 1.7, -2.0)
+    light["normal"], light["dims"] = (0.0, -1.0, 0.0), (0.5, 0.5)
+    ground = np.zeros(1, GROUND_PLANE)
+    ground["position"], ground["normal"], ground["dims"] = (0.0, -0.8, 0.0), (0.0, 1.0, 0.0), (5.0, 5.0)
+    ground["diffuse"], ground["metallic"], ground["roughness"] = (0.2, 0.2, 0.2), 0.01, 0.01
+    return build_scene(verts, rect_lights=light, ground=ground, sky=analytic_sky())

@@ -17,7 +17,8 @@
 // FLOATING-POINT CONTRACT (same as oracle/refshim/cpu_backend.hpp): IEEE binary32, one rounding
 // per operation, a*b+c fused exactly where the reference's source has it in one expression
 // (written here as explicit fmaf; this file is compiled with -ffp-contract=off), dot = fma chain
-// with the last component first, normalize = v * (1/sqrt(v.v)), min/max = fminf/fmaxf.
+// with the last component first, normalize = v * (1/sqrt(v.v)), min/max = fminf/fmaxf,
+// sin/cos/atan/atan2/asin/acos/exp/pow = include/nova_math.h (bit-reproducible on host and device).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "nova_hip.h"
+#include "nova_math.h"
 
 namespace {
 
@@ -301,7 +303,7 @@ inline float nz(float x) { return fmaxf(x, kNonZeroEps); }       // transforms.h
 inline f3 nz(f3 x) { return max3(x, splat(kNonZeroEps)); }      // transforms.hpp:54-56
 inline f3 reflect(f3 i, f3 n) { return fma3(n, -(2.0f * dot(n, i)), i); } // opencl/vector.hpp:23
 inline f3 spherical(float theta, float phi) {                   // transforms.hpp:46-48
-  return { sinf(theta) * cosf(phi), cosf(theta), sinf(theta) * sinf(phi) };
+  return { nova_sinf(theta) * nova_cosf(phi), nova_cosf(theta), nova_sinf(theta) * nova_sinf(phi) };
 }
 
 // kernels/material.hpp:15-29
@@ -313,8 +315,8 @@ f3 read_material(const Image& mats, const nova_triangle_meta& m, f2 tc, int inde
 }
 // kernels/material.hpp:31-35
 f3 read_sky(const Image& sky, f3 d) {
-  float u = fmaf(atan2f(d.z, d.x), kInvPi * 0.5f, 0.5f);
-  float v = fmaf(asinf(d.y), kInvPi, 0.5f);
+  float u = fmaf(nova_atan2f(d.z, d.x), kInvPi * 0.5f, 0.5f);
+  float v = fmaf(nova_asinf(d.y), kInvPi, 0.5f);
   return sample_linear(sky, u, v, 0, true);
 }
 // kernels/material.hpp:37-62
@@ -371,7 +373,7 @@ struct Brdf {
   }
   static f3 mix004(f3 dif, float met) { return fma3(dif - splat(0.04f), met, splat(0.04f)); }
   static f3 schlick(float c, f3 f0) {                                      // brdf.hpp:129-132
-    float p = powf(fmaxf(1.0f - c, 0.0f), 5.0f);
+    float p = nova_powf(fmaxf(1.0f - c, 0.0f), 5.0f);
     return fma3(splat(1.0f) - f0, p, f0);
   }
   f3 sample(uint32_t& rng) {                                               // brdf.hpp:41-77
@@ -385,11 +387,11 @@ struct Brdf {
     Mat3 basis = transpose(create_basis(normal));
     float phi = (2.0f * kPi) * xi1;
     if (xi0 <= est_t) {
-      float theta = atanf(roughness * sqrtf(xi2 / (1.0f - xi2)));
+      float theta = nova_atanf(roughness * sqrtf(xi2 / (1.0f - xi2)));
       m_normal = mul(basis, spherical(theta, phi));
       in_dir = reflect(-out_dir, m_normal);
     } else {
-      float theta = acosf(sqrtf(xi2));
+      float theta = nova_acosf(sqrtf(xi2));
       in_dir = mul(basis, spherical(theta, phi));
       m_normal = normalize(in_dir + out_dir);
     }
@@ -760,10 +762,10 @@ int oracle_kernel_post_process(const nova_scene_params* params, const float* col
         const float* p = color2 + 4 * (static_cast<size_t>(y) * width + x);
         c = { p[0], p[1], p[2] };
       }
-      f3 e = { expf(-c.x * params->exposure), expf(-c.y * params->exposure), expf(-c.z * params->exposure) };
+      f3 e = { nova_expf(-c.x * params->exposure), nova_expf(-c.y * params->exposure), nova_expf(-c.z * params->exposure) };
       f3 m = splat(1.0f) - e;
       const float g = 1.0f / 2.2f;
-      f3 o = { powf(m.x, g) * 255.0f, powf(m.y, g) * 255.0f, powf(m.z, g) * 255.0f };
+      f3 o = { nova_powf(m.x, g) * 255.0f, nova_powf(m.y, g) * 255.0f, nova_powf(m.z, g) * 255.0f };
       uint8_t* q = pixels + 4 * (static_cast<size_t>(y) * width + x);
       q[0] = static_cast<uint8_t>(static_cast<int>(o.x));
       q[1] = static_cast<uint8_t>(static_cast<int>(o.y));

@@ -22,7 +22,9 @@
 //     -cl-mad-enable; nothing else is re-associated;
 //   * the builtins below have the stated operation order (dot is an fma chain, normalize is a
 //     multiply by 1/sqrt, min/max are minNum/maxNum as v_min_f32/v_max_f32 and fminf/fmaxf are);
-//   * transcendental functions are the host libm's (only shading depends on them).
+//   * sin, cos, atan, atan2, asin, acos, exp, pow are the bit-reproducible implementations of
+//     include/nova_math.h (Cephes polynomials, every operation written out), because a one-ulp
+//     difference between a host libm and a device library is enough to send a path elsewhere.
 #ifndef NOVA_ORACLE_REFSHIM_CPU_BACKEND_HPP
 #define NOVA_ORACLE_REFSHIM_CPU_BACKEND_HPP
 
@@ -32,6 +34,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <type_traits>
+
+#include "nova_math.h"
 
 // ---- qualifiers (kernels/backend/opencl/kernel.hpp:4-9 defines the same names) -----------------
 #define DEVICE
@@ -109,16 +113,17 @@ inline float3 mix(float3 a, float3 b, float t) {
   return { __builtin_fmaf(d.x, t, a.x), __builtin_fmaf(d.y, t, a.y), __builtin_fmaf(d.z, t, a.z) };
 }
 
-inline float pow(float a, float b) { return ::powf(a, b); }
-inline float3 pow(float3 a, float b) { return { ::powf(a.x, b), ::powf(a.y, b), ::powf(a.z, b) }; }
-inline float exp(float a) { return ::expf(a); }
-inline float3 exp(float3 a) { return { ::expf(a.x), ::expf(a.y), ::expf(a.z) }; }
-inline float sin(float a) { return ::sinf(a); }
-inline float cos(float a) { return ::cosf(a); }
-inline float atan(float a) { return ::atanf(a); }
-inline float atan2(float a, float b) { return ::atan2f(a, b); }
-inline float asin(float a) { return ::asinf(a); }
-inline float acos(float a) { return ::acosf(a); }
+// elementary functions: the backend's published numeric contract (include/nova_math.h)
+inline float pow(float a, float b) { return nova_powf(a, b); }
+inline float3 pow(float3 a, float b) { return { nova_powf(a.x, b), nova_powf(a.y, b), nova_powf(a.z, b) }; }
+inline float exp(float a) { return nova_expf(a); }
+inline float3 exp(float3 a) { return { nova_expf(a.x), nova_expf(a.y), nova_expf(a.z) }; }
+inline float sin(float a) { return nova_sinf(a); }
+inline float cos(float a) { return nova_cosf(a); }
+inline float atan(float a) { return nova_atanf(a); }
+inline float atan2(float a, float b) { return nova_atan2f(a, b); }
+inline float asin(float a) { return nova_asinf(a); }
+inline float acos(float a) { return nova_acosf(a); }
 
 inline int isfinite(float a) { return __builtin_isfinite(a); }
 inline int3 isfinite(float3 a) {
