@@ -457,6 +457,33 @@ void nova_scene_copy(const void* handle, nova_bvh_node* bvh, nova_triangle_data*
 
 void nova_scene_free(void* handle) { delete static_cast<Built*>(handle); }
 
+// Hooks for the known answers of the reference's own unit tests
+// (tests/src/intersectables/aabb.cpp:7-64, triangle.cpp:8-21) on this builder's AABB / triangle
+// helpers.  out = {surface area, cost(n), centre.xyz}
+void nova_scene_test_aabb(const float* top, const float* bottom, uint64_t n, float* out) {
+  Box b { { top[0], top[1], top[2] }, { bottom[0], bottom[1], bottom[2] } };
+  out[0] = b.surface_area();
+  out[1] = b.cost(n);
+  V3 c = b.center();
+  out[2] = c.x; out[3] = c.y; out[4] = c.z;
+}
+// out = grown box {top.xyz, bottom.xyz}
+void nova_scene_test_aabb_grow(const float* top_a, const float* bottom_a, const float* top_b,
+                               const float* bottom_b, float* out) {
+  Box a { { top_a[0], top_a[1], top_a[2] }, { bottom_a[0], bottom_a[1], bottom_a[2] } };
+  Box b { { top_b[0], top_b[1], top_b[2] }, { bottom_b[0], bottom_b[1], bottom_b[2] } };
+  a.grow(b);
+  out[0] = a.top.x; out[1] = a.top.y; out[2] = a.top.z;
+  out[3] = a.bottom.x; out[4] = a.bottom.y; out[5] = a.bottom.z;
+}
+// out = bounds {top.xyz, bottom.xyz} of the triangle v[0..8]
+void nova_scene_test_tri_bounds(const float* v, float* out) {
+  Tri t { { v[0], v[1], v[2] }, { v[3], v[4], v[5] }, { v[6], v[7], v[8] } };
+  Box b = t.bounds();
+  out[0] = b.top.x; out[1] = b.top.y; out[2] = b.top.z;
+  out[3] = b.bottom.x; out[4] = b.bottom.y; out[5] = b.bottom.z;
+}
+
 // Layout self-check for the Python bindings.
 void nova_scene_struct_sizes(int32_t* out) {
   out[0] = sizeof(nova_bvh_node);

@@ -55,6 +55,7 @@ struct PackedScene {
   uint32_t n_packed = 0;
   uint32_t n_tris = 0;
   uint32_t stack_need = 0;
+  float radius = 1.0f;
   float root_top[3], root_bot[3];
 };
 
@@ -145,34 +146,62 @@ void collect_events() {
 }
 
 // ---- BVH repack: FlatBVHNode[] (DFS pre-order, left child adjacent; src/bvh/bvh.cpp:211-249)
-// -> dense array of 64-byte box-pair nodes.
+// -> dense array of 64-byte box-pair nodes, plus the per-node cull slack (traverse.hpp).
 struct Packer {
   const std::vector<nova_bvh_node>& in;
   uint32_t n_tris;
   std::vector<Node64> out;
+  std::vector<LeafRec> leaves;
+  // child k of packed node n: leaf index (>= 0) or -1 when it is packed node child_node[n][k]
+  std::vector<int32_t> child_leaf[2];
+  std::vector<uint32_t> child_node[2];
   uint32_t max_depth = 0;
   bool bad = false;
 
   static bool is_leaf(const nova_bvh_node& n) { return !(n.bottom_num_right.w >= 0.0f); }
 
-  static void set_child(Node64& nd, int k, const nova_float4& top, const nova_float4& bot, uint32_t ref) {
+  uint32_t new_node() {
+    out.emplace_back();
+    for (int k = 0; k < 2; k++) {
+      child_leaf[k].push_back(-1);
+      child_node[k].push_back(0);
+    }
+    return static_cast<uint32_t>(out.size() - 1);
+  }
+
+  void set_child(uint32_t slot, int k, const nova_float4& top, const nova_float4& bot, uint32_t ref, int32_t leaf) {
+    Node64& nd = out[slot];
     if (k == 0) {
       nd.a = make_float4(top.x, top.y, top.z, __builtin_bit_cast(float, ref));
       nd.b.x = bot.x; nd.b.y = bot.y; nd.b.z = bot.z;
     } else {
-      nd.c = make_float4(top.x, top.y, top.z, 0.0f);
+      nd.c.x = top.x; nd.c.y = top.y; nd.c.z = top.z;
       nd.d = make_float4(bot.x, bot.y, bot.z, 0.0f);
       nd.b.w = __builtin_bit_cast(float, ref);
     }
+    child_leaf[k][slot] = leaf;
+    child_node[k][slot] = ref;
   }
-  static void set_empty_child(Node64& nd, int k) {
+  void set_empty_child(uint32_t slot, int k) {
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     nova_float4 v = { qnan, qnan, qnan, 0.0f };
-    set_child(nd, k, v, v, kLeafBit); // never entered: a NaN box fails `tmin <= tmax`
+    set_child(slot, k, v, v, kLeafBit, -2); // never entered: a NaN box fails `tmin <= tmax`
   }
 
-  // reference of the subtree rooted at original node i (depth = number of packed levels above)
-  uint32_t ref_of(uint32_t i, uint32_t depth) {
+  int32_t add_leaf(const nova_bvh_node& n, uint32_t off, uint32_t cnt) {
+    LeafRec r;
+    r.first = off;
+    r.count = cnt;
+    r.top[0] = n.top_offset_left.x; r.top[1] = n.top_offset_left.y; r.top[2] = n.top_offset_left.z;
+    r.bot[0] = n.bottom_num_right.x; r.bot[1] = n.bottom_num_right.y; r.bot[2] = n.bottom_num_right.z;
+    leaves.push_back(r);
+    return static_cast<int32_t>(leaves.size() - 1);
+  }
+
+  // reference of the subtree rooted at original node i (depth = number of packed levels above);
+  // *leaf receives the leaf index when the subtree is a single leaf reference
+  uint32_t ref_of(uint32_t i, uint32_t depth, int32_t* leaf) {
+    *leaf = -1;
     if (bad) return kLeafBit;
     const nova_bvh_node& n = in[i];
     if (is_leaf(n)) {
@@ -181,7 +210,10 @@ struct Packer {
       const uint32_t off = static_cast<uint32_t>(foff), cnt = static_cast<uint32_t>(fcnt);
       if (static_cast<uint64_t>(off) + cnt > n_tris) { bad = true; return kLeafBit; }
       max_depth = std::max(max_depth, depth);
-      if (cnt <= kMaxLeafTris) return kLeafBit | ((cnt - 1u) << 24) | off;
+      if (cnt <= kMaxLeafTris) {
+        *leaf = add_leaf(n, off, cnt);
+        return kLeafBit | ((cnt - 1u) << 24) | off;
+      }
       // oversized leaf: chain of box-pair nodes, each holding one chunk and the rest
       return chain(n, off, cnt, depth);
     }
@@ -192,29 +224,31 @@ struct Packer {
       bad = true;
       return kLeafBit;
     }
-    const uint32_t slot = static_cast<uint32_t>(out.size());
-    out.emplace_back();
-    const uint32_t r0 = ref_of(i + 1, depth + 1);
-    const uint32_t r1 = ref_of(right, depth + 1);
-    set_child(out[slot], 0, in[i + 1].top_offset_left, in[i + 1].bottom_num_right, r0);
-    set_child(out[slot], 1, in[right].top_offset_left, in[right].bottom_num_right, r1);
+    const uint32_t slot = new_node();
+    int32_t l0, l1;
+    const uint32_t r0 = ref_of(i + 1, depth + 1, &l0);
+    const uint32_t r1 = ref_of(right, depth + 1, &l1);
+    set_child(slot, 0, in[i + 1].top_offset_left, in[i + 1].bottom_num_right, r0, l0);
+    set_child(slot, 1, in[right].top_offset_left, in[right].bottom_num_right, r1, l1);
     return slot;
   }
 
   uint32_t chain(const nova_bvh_node& leaf, uint32_t off, uint32_t cnt, uint32_t depth) {
-    const uint32_t slot = static_cast<uint32_t>(out.size());
-    out.emplace_back();
+    const uint32_t slot = new_node();
     const uint32_t head = kLeafBit | ((kMaxLeafTris - 1u) << 24) | off;
+    const int32_t lh = add_leaf(leaf, off, kMaxLeafTris);
     const uint32_t rest = cnt - kMaxLeafTris;
     uint32_t r1;
+    int32_t l1 = -1;
     if (rest <= kMaxLeafTris) {
       r1 = kLeafBit | ((rest - 1u) << 24) | (off + kMaxLeafTris);
+      l1 = add_leaf(leaf, off + kMaxLeafTris, rest);
       max_depth = std::max(max_depth, depth + 1);
     } else {
       r1 = chain(leaf, off + kMaxLeafTris, rest, depth + 1);
     }
-    set_child(out[slot], 0, leaf.top_offset_left, leaf.bottom_num_right, head);
-    set_child(out[slot], 1, leaf.top_offset_left, leaf.bottom_num_right, r1);
+    set_child(slot, 0, leaf.top_offset_left, leaf.bottom_num_right, head, lh);
+    set_child(slot, 1, leaf.top_offset_left, leaf.bottom_num_right, r1, l1);
     return slot;
   }
 };
@@ -240,18 +274,60 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   Packer pk { host, static_cast<uint32_t>(n_tris) };
   pk.out.reserve(n_nodes / 2 + 2);
   const nova_bvh_node& root = host[0];
+  int32_t root_leaf = -1;
   if (Packer::is_leaf(root)) {
     // a single-leaf tree: give it a parent whose second child is never entered
-    pk.out.emplace_back();
-    const uint32_t r0 = pk.ref_of(0, 1);
-    // ref_of may have appended chain nodes; out[0] stays the synthetic root
-    Packer::set_child(pk.out[0], 0, root.top_offset_left, root.bottom_num_right, r0);
-    Packer::set_empty_child(pk.out[0], 1);
+    const uint32_t slot = pk.new_node();
+    const uint32_t r0 = pk.ref_of(0, 1, &root_leaf);
+    pk.set_child(slot, 0, root.top_offset_left, root.bottom_num_right, r0, root_leaf);
+    pk.set_empty_child(slot, 1);
   } else {
-    pk.ref_of(0, 0);
+    pk.ref_of(0, 0, &root_leaf);
   }
   if (pk.bad || pk.out.empty()) return NOVA_HIP_E_BAD_SCENE;
   if (pk.max_depth > 64) return NOVA_HIP_E_TOO_LARGE; // the reference's own STACK_SIZE (kernels/constants.hpp:8)
+
+  // scene radius: largest |coordinate| of the root box
+  float radius = 0.0f;
+  const float rc[6] = { root.top_offset_left.x, root.top_offset_left.y, root.top_offset_left.z,
+                        root.bottom_num_right.x, root.bottom_num_right.y, root.bottom_num_right.z };
+  for (float c : rc) radius = std::max(radius, std::fabs(c));
+  if (!(radius > 0.0f) || !std::isfinite(radius)) radius = 1.0f;
+
+  // per-leaf slack on the device (it reads every Woop matrix), then max over subtrees on the host
+  const size_t n_leaves = pk.leaves.size();
+  std::vector<float> leaf_e(n_leaves);
+  {
+    LeafRec* d_leaves = nullptr;
+    float* d_e = nullptr;
+    HIP_TRY(hipMalloc(&d_leaves, n_leaves * sizeof(LeafRec)));
+    hipError_t e = hipMalloc(&d_e, n_leaves * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_leaves, pk.leaves.data(), n_leaves * sizeof(LeafRec), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      const unsigned blocks = static_cast<unsigned>((n_leaves + 255) / 256);
+      hipLaunchKernelGGL(k_leaf_slack, dim3(blocks), dim3(256), 0, g.stream,
+                         reinterpret_cast<const float4*>(tris), d_leaves, static_cast<uint32_t>(n_leaves), radius, d_e);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e == hipSuccess) e = hipMemcpy(leaf_e.data(), d_e, n_leaves * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d_leaves);
+    (void) hipFree(d_e);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  // packed nodes are in DFS pre-order (children after parents): one reverse sweep
+  std::vector<float> node_e(pk.out.size(), 0.0f);
+  const float e_round = radius * kSlabRoundingSlack;
+  for (size_t n = pk.out.size(); n-- > 0;) {
+    float e = 0.0f;
+    for (int k = 0; k < 2; k++) {
+      const int32_t l = pk.child_leaf[k][n];
+      if (l >= 0) e = std::max(e, leaf_e[l]);
+      else if (l == -1) e = std::max(e, node_e[pk.child_node[k][n]]);
+    }
+    node_e[n] = e;
+    pk.out[n].c.w = e + e_round;
+  }
 
   PackedScene s;
   s.bvh_ptr = bvh;
@@ -261,6 +337,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   s.n_packed = static_cast<uint32_t>(pk.out.size());
   s.n_tris = static_cast<uint32_t>(n_tris);
   s.stack_need = pk.max_depth;
+  s.radius = radius;
   s.root_top[0] = root.top_offset_left.x; s.root_top[1] = root.top_offset_left.y; s.root_top[2] = root.top_offset_left.z;
   s.root_bot[0] = root.bottom_num_right.x; s.root_bot[1] = root.bottom_num_right.y; s.root_bot[2] = root.bottom_num_right.z;
   HIP_TRY(hipMalloc(&s.nodes, pk.out.size() * sizeof(Node64)));
@@ -293,6 +370,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A) {
   A.tris = reinterpret_cast<const float4*>(s.tri_ptr);
   std::memcpy(A.root_top, s.root_top, sizeof(A.root_top));
   std::memcpy(A.root_bot, s.root_bot, sizeof(A.root_bot));
+  A.inv_radius = 1.0f / s.radius;
   A.work_counters = g.d_counters;
   const bool cull = g.opt_traversal == 0, count = g.opt_count_work != 0;
   hipEvent_t e0 = next_event(), e1 = next_event();

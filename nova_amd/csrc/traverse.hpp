@@ -18,10 +18,18 @@
 // Semantics: the boxes tested are exactly the reference's (same operations, same order of
 // operands), so the set of triangles reachable is the reference's.  Closest hit = min t over
 // reachable triangles, ties -> lowest triangle index (the reference visits triangles in
-// increasing index order with a strict `t < length`).  CULL=true visits the nearer child first and
-// skips subtrees wholly behind the origin or beyond the current hit, with a safety margin
-// (kCull*) far above the rounding of the slab and Woop arithmetic; CULL=false is the
-// reference's own walk (fixed order, no culling) and is kept as the validation mode.
+// increasing index order with a strict `t < length`).  CULL=false is the reference's own walk
+// (fixed order, no culling) and is kept as the validation mode.  CULL=true visits the nearer child
+// first and skips subtrees wholly behind the origin or beyond the current hit.  That cull is made
+// conservative with respect to the Woop ARITHMETIC, not the ideal geometry: Nova's Woop matrix
+// [e1 e2 n-v1 v1]^-1 (src/intersectables/intersectable_manager.cpp:137-142) is singular where
+// n.v1 = 1, so real scenes carry matrices with entries ~1e7 whose float evaluation accepts hits
+// well outside the triangle's box.  At upload k_leaf_slack measures, for every triangle, how far
+// the set of points its test can accept reaches beyond its leaf box: the triangle the float
+// matrix really encodes (its inverse, in double) plus the rounding of the barycentric
+// evaluation.  Each node stores e = max of that over its subtree (+ the slab test's own
+// rounding); a box is culled against [0, best t] only after being widened by e on every side
+// (tmin - e*max|1/d|, tmax + e*max|1/d|), so every hit the reference accepts is still visited.
 #pragma once
 
 #include "device_math.hpp"
@@ -31,15 +39,20 @@ namespace nova_hip {
 struct __attribute__((aligned(64))) Node64 {
   float4 a; // child0 box max.xyz, w = child0 reference (bits)
   float4 b; // child0 box min.xyz, w = child1 reference (bits)
-  float4 c; // child1 box max.xyz, w = unused
+  float4 c; // child1 box max.xyz, w = cull slack e of this node's subtree (world units)
   float4 d; // child1 box min.xyz, w = unused
+};
+
+struct LeafRec {
+  uint32_t first, count;
+  float top[3], bot[3];
 };
 
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kMaxLeafTris = 128;
-constexpr float kCullRel = 1e-4f;    // relative slack on the current hit distance
-constexpr float kCullAbs = 1e-4f;    // absolute slack on the current hit distance
-constexpr float kCullBehind = -1e-3f; // a box is "behind" only if it ends before this t
+constexpr float kCullRel = 0x1p-20f;          // relative slack on the current hit distance
+constexpr float kEvalRounding = 0x1p-20f;     // bound on the fma-chain rounding (gamma_4 = 2^-22, x4)
+constexpr float kSlabRoundingSlack = 0x1p-19f; // slab test rounding, as a fraction of the scene radius
 
 struct TraverseArgs {
   const Node64* nodes;
@@ -54,8 +67,69 @@ struct TraverseArgs {
   uint32_t kinds;  // work items = n_items * kinds; item w -> slot (w / n) * stride + (w % n)
   uint32_t stride;
   uint32_t* queue_head;
+  float inv_radius;                  // 1 / largest |coordinate| of the root box
   unsigned long long* work_counters; // [0] node fetches, [1] triangle tests (COUNT only)
 };
+
+// Per-leaf cull slack (see the header comment).  For a ray with |origin| <= R and a hit inside
+// the scene box, the barycentric u = ox + t*dx is evaluated with absolute error
+// <= kEvalRounding * (3R * sum|m.x_i| + |m.x.w|) (same for v); an error du moves the accepted
+// point by du * |e1'|, e1' being the edge the matrix really encodes.  Rays starting farther away
+// scale the slack by |origin|/R in trace_one.
+__global__ __launch_bounds__(256) void k_leaf_slack(const float4* tris, const LeafRec* leaves,
+                                                    uint32_t n_leaves, float radius, float* out) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_leaves) return;
+  const LeafRec L = leaves[l];
+  const double inf = __builtin_huge_val();
+  double worst = 0.0;
+  for (uint32_t i = L.first; i < L.first + L.count; i++) {
+    const float4 mx = tris[3 * static_cast<size_t>(i)], my = tris[3 * static_cast<size_t>(i) + 1],
+                 mz = tris[3 * static_cast<size_t>(i) + 2];
+    const double a[3][3] = { { mx.x, mx.y, mx.z }, { my.x, my.y, my.z }, { mz.x, mz.y, mz.z } };
+    const double w[3] = { mx.w, my.w, mz.w };
+    // inverse of the 3x3 part by cofactors
+    double c[3][3];
+    c[0][0] = a[1][1] * a[2][2] - a[1][2] * a[2][1];
+    c[0][1] = a[1][2] * a[2][0] - a[1][0] * a[2][2];
+    c[0][2] = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    c[1][0] = a[0][2] * a[2][1] - a[0][1] * a[2][2];
+    c[1][1] = a[0][0] * a[2][2] - a[0][2] * a[2][0];
+    c[1][2] = a[0][1] * a[2][0] - a[0][0] * a[2][1];
+    c[2][0] = a[0][1] * a[1][2] - a[0][2] * a[1][1];
+    c[2][1] = a[0][2] * a[1][0] - a[0][0] * a[1][2];
+    c[2][2] = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    const double det = a[0][0] * c[0][0] + a[0][1] * c[0][1] + a[0][2] * c[0][2];
+    double slack = inf;
+    if (det != 0.0 && det == det && __builtin_fabs(det) < inf) {
+      const double id = 1.0 / det;
+      // inv[r][k] = c[k][r] / det; column k of the inverse = image of unit vector k
+      double e1[3], e2[3], v1[3];
+      for (int r = 0; r < 3; r++) {
+        e1[r] = c[0][r] * id;
+        e2[r] = c[1][r] * id;
+        v1[r] = -(c[0][r] * w[0] + c[1][r] * w[1] + c[2][r] * w[2]) * id;
+      }
+      double stick = 0.0;
+      for (int r = 0; r < 3; r++) {
+        const double p[3] = { v1[r], v1[r] + e1[r], v1[r] + e2[r] };
+        for (int k = 0; k < 3; k++) {
+          stick = __builtin_fmax(stick, p[k] - static_cast<double>(L.top[r]));
+          stick = __builtin_fmax(stick, static_cast<double>(L.bot[r]) - p[k]);
+        }
+      }
+      const double le1 = __builtin_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+      const double le2 = __builtin_sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+      const double r3 = 3.0 * static_cast<double>(radius);
+      const double du = kEvalRounding * (r3 * (__builtin_fabs(a[0][0]) + __builtin_fabs(a[0][1]) + __builtin_fabs(a[0][2])) + __builtin_fabs(w[0]));
+      const double dv = kEvalRounding * (r3 * (__builtin_fabs(a[1][0]) + __builtin_fabs(a[1][1]) + __builtin_fabs(a[1][2])) + __builtin_fabs(w[1]));
+      slack = stick + du * le1 + dv * le2;
+      if (!(slack == slack)) slack = inf;
+    }
+    worst = __builtin_fmax(worst, slack);
+  }
+  out[l] = worst < 3.0e38 ? static_cast<float>(worst) * 1.0000002f + 1e-30f : __builtin_huge_valf();
+}
 
 struct RayState {
   V3 o, d, inv, nio;
@@ -114,7 +188,12 @@ __device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
   if (!slab(r, rt, rb, tmin, tmax)) return;
 
-  float far_limit = fma_(h.t, kCullRel, h.t) + kCullAbs;
+  // slack multiplier of this ray: max |1/d| (how far a slab bound moves when the box is widened
+  // by one unit), scaled up for origins outside the scene radius
+  const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
+  const float slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
+                            max_(1.0f, o_inf * A.inv_radius);
+  float far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
   uint32_t sp = 0;
   uint32_t cur = 0;
   while (true) {
@@ -126,8 +205,9 @@ __device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)
       bool h0 = slab(r, na, nb, tmin0, tmax0);
       bool h1 = slab(r, nc, ndd, tmin1, tmax1);
       if (CULL) {
-        h0 = h0 && (tmax0 >= kCullBehind) && (tmin0 <= far_limit);
-        h1 = h1 && (tmax1 >= kCullBehind) && (tmin1 <= far_limit);
+        const float es = nc.w * slack_scale;
+        h0 = h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
+        h1 = h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
       }
       const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
       if (h0 && h1) {
@@ -147,7 +227,7 @@ __device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)
         if (COUNT) n_tris++;
         if (woop(r, h, static_cast<int>(i), m[0], m[1], m[2])) {
           if (anyhit) { done = true; break; }
-          far_limit = fma_(h.t, kCullRel, h.t) + kCullAbs;
+          far_limit = fma_(h.t, kCullRel, h.t);
         }
       }
       if (done) return;

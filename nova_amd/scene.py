@@ -378,8 +378,8 @@ def grid_to_triangles(P: np.ndarray, wrap_u=True, wrap_v=True) -> np.ndarray:
     a, b = np.meshgrid(iu, iv, indexing="ij")
     a2, b2 = (a + 1) % nu, (b + 1) % nv
     p00, p10, p01, p11 = P[a, b], P[a2, b], P[a, b2], P[a2, b2]
-    t1 = np.stack([p00, p10, p11], -2)
-    t2 = np.stack([p00, p11, p01], -2)
+    t1 = np.stack([p00, p11, p10], -2)
+    t2 = np.stack([p00, p01, p11], -2)
     return np.concatenate([t1.reshape(-1, 9), t2.reshape(-1, 9)]).astype(np.float32)
 
 
@@ -527,3 +527,17 @@ def dragon_standin(nu=660, nv=660) -> Scene:
     ground["position"], ground["normal"], ground["dims"] = (0.0, -0.8, 0.0), (0.0, 1.0, 0.0), (5.0, 5.0)
     ground["diffuse"], ground["metallic"], ground["roughness"] = (0.2, 0.2, 0.2), 0.01, 0.01
     return build_scene(verts, rect_lights=light, ground=ground, sky=analytic_sky())
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's hex dump format for FlatBVHNode / Triangle (src/bvh/bvh.cpp:251-281,
+# src/intersectables/triangle.cpp:27-55): the float bit patterns as hex words separated by blanks.
+# ------------------------------------------------------------------------------------------------
+def to_hex_words(arr: np.ndarray) -> str:
+    words = np.ascontiguousarray(arr).view(np.uint32).reshape(-1)
+    return "".join(f"{w:x} " for w in words)
+
+
+def from_hex_words(text: str, dtype) -> np.ndarray:
+    words = np.array([int(t, 16) for t in text.split()], dtype=np.uint32)
+    return words.view(np.dtype(dtype))

@@ -103,3 +103,16 @@ def trace_rays(scene, point_tmax, dir_flags, ordered=False, counters=None):
                                  _p(counters))
     assert rc == 0
     return hits
+
+
+MATH_FNS = {"sin": 0, "cos": 1, "atan": 2, "atan2": 3, "asin": 4, "acos": 5, "exp": 6, "log": 7,
+            "pow": 8}
+
+
+def math_fn(name: str, x, y=None):
+    """include/nova_math.h evaluated on the host."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = x if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.empty_like(x)
+    lib().oracle_math(ctypes.c_int(MATH_FNS[name]), _p(x), _p(y), _p(out), ctypes.c_uint64(x.size))
+    return out

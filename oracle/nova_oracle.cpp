@@ -193,23 +193,103 @@ bool find_intersection_reference(const nova_triangle_data* tris, const nova_bvh_
   return best.tri != -1;
 }
 
+// Cull slack of every subtree, for the ordered traversal below.  Nova's Woop matrices are
+// ill-conditioned where n.v1 ~ 1 (src/intersectables/intersectable_manager.cpp:137-142: the third
+// column of the inverted matrix is n - v1), so the float evaluation of a triangle test can accept
+// points outside the triangle's box; an exact distance cull would then skip hits the reference
+// finds.  slack(triangle) = how far the triangle the matrix really encodes (double-precision
+// inverse) sticks out of its leaf box + the world-space effect of the barycentric rounding
+// (<= 2^-20 (3R sum|m_i| + |m_w|) per coordinate, R = scene radius); slack(node) = max over its
+// subtree + 2^-19 R for the slab test's own rounding.
+struct Slack {
+  std::vector<float> node;
+  float inv_radius = 1.0f;
+};
+
+double triangle_slack(const nova_triangle_data& m, const nova_bvh_node& leaf, double radius) {
+  const double a[3][3] = { { m.x.x, m.x.y, m.x.z }, { m.y.x, m.y.y, m.y.z }, { m.z.x, m.z.y, m.z.z } };
+  const double w[3] = { m.x.w, m.y.w, m.z.w };
+  double c[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < 3; k++) {
+      const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      c[r][k] = a[r1][k1] * a[r2][k2] - a[r1][k2] * a[r2][k1];
+    }
+  const double det = a[0][0] * c[0][0] + a[0][1] * c[0][1] + a[0][2] * c[0][2];
+  if (!(det != 0.0) || !std::isfinite(det)) return HUGE_VAL;
+  double e1[3], e2[3], v1[3];
+  for (int r = 0; r < 3; r++) {
+    e1[r] = c[0][r] / det;
+    e2[r] = c[1][r] / det;
+    v1[r] = -(c[0][r] * w[0] + c[1][r] * w[1] + c[2][r] * w[2]) / det;
+  }
+  const double top[3] = { leaf.top_offset_left.x, leaf.top_offset_left.y, leaf.top_offset_left.z };
+  const double bot[3] = { leaf.bottom_num_right.x, leaf.bottom_num_right.y, leaf.bottom_num_right.z };
+  double stick = 0.0;
+  for (int r = 0; r < 3; r++) {
+    const double p[3] = { v1[r], v1[r] + e1[r], v1[r] + e2[r] };
+    for (double q : p) stick = std::max({ stick, q - top[r], bot[r] - q });
+  }
+  const double le1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  const double le2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+  const double k = 0x1p-20, r3 = 3.0 * radius;
+  const double du = k * (r3 * (std::fabs(a[0][0]) + std::fabs(a[0][1]) + std::fabs(a[0][2])) + std::fabs(w[0]));
+  const double dv = k * (r3 * (std::fabs(a[1][0]) + std::fabs(a[1][1]) + std::fabs(a[1][2])) + std::fabs(w[1]));
+  const double s = stick + du * le1 + dv * le2;
+  return s == s ? s : HUGE_VAL;
+}
+
+double subtree_slack(const nova_triangle_data* tris, const nova_bvh_node* bvh, uint32_t i, double radius,
+                     std::vector<float>& out) {
+  if (out.size() <= i) out.resize(i + 1, 0.0f);
+  const nova_bvh_node& n = bvh[i];
+  double s = 0.0;
+  if (n.bottom_num_right.w < 0.0f) {
+    const uint32_t off = static_cast<uint32_t>(n.top_offset_left.w), num = static_cast<uint32_t>(-n.bottom_num_right.w);
+    for (uint32_t t = off; t < off + num; t++) s = std::max(s, triangle_slack(tris[t], n, radius));
+  } else {
+    s = std::max(subtree_slack(tris, bvh, i + 1, radius, out),
+                 subtree_slack(tris, bvh, static_cast<uint32_t>(n.bottom_num_right.w), radius, out));
+  }
+  const double total = s * 1.0000002 + 0x1p-19 * radius;
+  out[i] = total < 3.0e38 ? static_cast<float>(total) : HUGE_VALF;
+  return s;
+}
+
+Slack compute_slack(const nova_triangle_data* tris, const nova_bvh_node* bvh) {
+  Slack sl;
+  double radius = 0.0;
+  const float rc[6] = { bvh[0].top_offset_left.x, bvh[0].top_offset_left.y, bvh[0].top_offset_left.z,
+                        bvh[0].bottom_num_right.x, bvh[0].bottom_num_right.y, bvh[0].bottom_num_right.z };
+  for (float c : rc) radius = std::max(radius, static_cast<double>(std::fabs(c)));
+  if (!(radius > 0.0) || !std::isfinite(radius)) radius = 1.0;
+  sl.inv_radius = static_cast<float>(1.0 / radius);
+  subtree_slack(tris, bvh, 0, radius, sl.node);
+  return sl;
+}
+
 // Ordered, hit-distance-culled traversal of the same tree (near child first; a subtree is
-// skipped when its box lies wholly behind the origin or beyond the current hit).  Returns the
-// same hit as the reference walk (min t, ties -> lowest index); used for the algorithmic work
-// model N_node / N_tri of SURVEY.md §8(d).  Here one "node" = one box test, as in the reference.
+// skipped when its box, widened by the subtree's slack, lies wholly behind the origin or beyond
+// the current hit).  Returns the same hit as the reference walk (min t, ties -> lowest index);
+// used for the algorithmic work model N_node / N_tri of SURVEY.md §8(d).  One "node" = one box
+// test, as in the reference.
 bool find_intersection_ordered(const nova_triangle_data* tris, const nova_bvh_node* bvh, const Ray& ray,
-                               Hit& best, bool anyhit, WorkCount* wc) {
+                               Hit& best, bool anyhit, WorkCount* wc, const Slack& slack) {
   struct Entry { uint32_t node; float tmin; };
   std::vector<Entry> stack;
   stack.reserve(64);
+  const float o_inf = fmaxf(fabsf(ray.origin.x), fmaxf(fabsf(ray.origin.y), fabsf(ray.origin.z)));
+  const float scale = fmaxf(fabsf(ray.inv_direction.x), fmaxf(fabsf(ray.inv_direction.y), fabsf(ray.inv_direction.z))) *
+                      fmaxf(1.0f, o_inf * slack.inv_radius);
+  auto limit = [&]() { return fmaf(fabsf(best.length), 0x1p-20f, best.length); };
   float a, b;
   if (wc) wc->nodes++;
   if (!slab(ray, xyz(bvh[0].top_offset_left), xyz(bvh[0].bottom_num_right), a, b)) return false;
-  stack.push_back({ 0u, a });
+  stack.push_back({ 0u, -HUGE_VALF });
   while (!stack.empty()) {
     Entry e = stack.back();
     stack.pop_back();
-    if (e.tmin > best.length) continue;
+    if (e.tmin > limit()) continue;
     const nova_bvh_node& n = bvh[e.node];
     if (n.bottom_num_right.w < 0.0f) {
       uint32_t off = static_cast<uint32_t>(n.top_offset_left.w);
@@ -226,7 +306,9 @@ bool find_intersection_ordered(const nova_triangle_data* tris, const nova_bvh_no
     for (int k = 0; k < 2; k++) {
       if (wc) wc->nodes++;
       ok[k] = slab(ray, xyz(bvh[c[k]].top_offset_left), xyz(bvh[c[k]].bottom_num_right), tm[k], tx[k]);
-      ok[k] = ok[k] && tx[k] >= 0.0f && tm[k] <= best.length;
+      const float es = slack.node[c[k]] * scale;
+      tm[k] = tm[k] - es; // entry into the widened box
+      ok[k] = ok[k] && tx[k] + es >= 0.0f && tm[k] <= limit();
     }
     if (ok[0] && ok[1]) {
       int near = tm[1] < tm[0] ? 1 : 0;
@@ -455,9 +537,12 @@ struct RayCount {
 // kernels/raytrace.hpp:104-298.  max_depth = 0 reproduces the reference (unbounded); max_depth
 // = d stops a path after it has shaded (incl. direct lighting) its d-th segment.
 f3 trace_ray(uint32_t& rng, const nova_scene_params& P, int px, int py, const SceneView& S,
-             bool denoise, f3& albedo_feature, f3& normal_feature, uint32_t max_depth, bool ordered,
+             bool denoise, f3& albedo_feature, f3& normal_feature, uint32_t max_depth, const Slack* slack,
              RayCount& rc, bool count_work) {
-  auto find = ordered ? find_intersection_ordered : find_intersection_reference;
+  auto find = [&](const nova_triangle_data* t, const nova_bvh_node* b, const Ray& r, Hit& h, bool any, WorkCount* w) {
+    return slack ? find_intersection_ordered(t, b, r, h, any, w, *slack)
+                 : find_intersection_reference(t, b, r, h, any, w);
+  };
   WorkCount* wc = count_work ? &rc.work : nullptr;
   float jx = rnd(rng), jy = rnd(rng);
   const nova_eye_coords& E = P.eye_coords;
@@ -675,6 +760,24 @@ void oracle_brdf(const float* o, const float* n, const float* dif, float met, fl
   std::memcpy(out, r, sizeof(r));
 }
 
+// include/nova_math.h on arrays, for tests/test_math.py.
+// fn: 0 sin 1 cos 2 atan 3 atan2(x,y) 4 asin 5 acos 6 exp 7 log 8 pow(x,y)
+void oracle_math(int fn, const float* x, const float* y, float* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) {
+    switch (fn) {
+      case 0: out[i] = nova_sinf(x[i]); break;
+      case 1: out[i] = nova_cosf(x[i]); break;
+      case 2: out[i] = nova_atanf(x[i]); break;
+      case 3: out[i] = nova_atan2f(x[i], y[i]); break;
+      case 4: out[i] = nova_asinf(x[i]); break;
+      case 5: out[i] = nova_acosf(x[i]); break;
+      case 6: out[i] = nova_expf(x[i]); break;
+      case 7: out[i] = nova_logf(x[i]); break;
+      default: out[i] = nova_powf(x[i], y[i]); break;
+    }
+  }
+}
+
 // kernels/kernels.cu:9-40.  counters (optional, 8 x uint64): primary, bounce, shadow rays,
 // shaded segments, node visits, triangle tests.  ordered = 1 selects the culled traversal.
 int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float* temp_color1,
@@ -689,6 +792,9 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
                 { materials, (int) mat_w, (int) mat_h, (int) mat_layers }, { sky, (int) sky_w, (int) sky_h, 1 } };
   uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
   row_end = std::min(row_end, height);
+  Slack slack;
+  if (ordered) slack = compute_slack(tris, bvh);
+  const Slack* slack_ptr = ordered ? &slack : nullptr;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c0, c1, c2, c3, c4, c5) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
   for (int y = (int) row_begin; y < (int) row_end; y++) {
     RayCount rc;
@@ -696,7 +802,7 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
       uint32_t rng = wang_hash(static_cast<uint32_t>(y) * width + static_cast<uint32_t>(x) + wang_hash(time));
       f3 albedo { 0, 0, 0 }, normal { 0, 0, 0 };
       f3 c = trace_ray(rng, *params, x, y, S, denoise_available != 0, albedo, normal, max_depth,
-                       ordered != 0, rc, count_work != 0);
+                       slack_ptr, rc, count_work != 0);
       size_t o = 4 * (static_cast<size_t>(y) * width + x);
       temp_color1[o] = c.x; temp_color1[o + 1] = c.y; temp_color1[o + 2] = c.z; temp_color1[o + 3] = 1.0f;
       if (denoise_available) {
@@ -781,6 +887,8 @@ int oracle_kernel_post_process(const nova_scene_params* params, const float* col
 int oracle_trace_rays(const nova_triangle_data* tris, const nova_bvh_node* bvh, const float* point_tmax,
                       const float* dir_flags, float* hits, uint64_t n_rays, int mode, uint64_t* counters) {
   uint64_t cn = 0, ct = 0;
+  Slack slack;
+  if (mode) slack = compute_slack(tris, bvh);
 #pragma omp parallel for schedule(dynamic, 256) reduction(+ : cn, ct) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
   for (int64_t i = 0; i < (int64_t) n_rays; i++) {
     uint32_t flags;
@@ -790,8 +898,8 @@ int oracle_trace_rays(const nova_triangle_data* tris, const nova_bvh_node* bvh, 
     Hit h;
     h.length = point_tmax[4 * i + 3];
     WorkCount wc;
-    (mode ? find_intersection_ordered : find_intersection_reference)(tris, bvh, ray, h, (flags & 1u) != 0,
-                                                                     counters ? &wc : nullptr);
+    if (mode) find_intersection_ordered(tris, bvh, ray, h, (flags & 1u) != 0, counters ? &wc : nullptr, slack);
+    else find_intersection_reference(tris, bvh, ray, h, (flags & 1u) != 0, counters ? &wc : nullptr);
     cn += wc.nodes;
     ct += wc.tris;
     hits[4 * i] = h.length;
