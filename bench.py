@@ -1,0 +1,220 @@
+"""Benchmark of the hot path: Mrays/s of the MI355X ray-tracing backend.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one sample of the frame through the reference's per-sample schedule
+(kernel_raytrace -> kernel_accumulate -> copy prev image -> kernel_post_process,
+reference src/core/raytracer.cpp:169-262) with all inputs resident in HBM.
+
+Workload at N = 1 (BASELINE.json configs[1]): dragon scene — the real asset is absent from the
+reference tree, so its stand-in is used: a seeded 871,200-triangle displaced torus knot with the
+light, ground plane, camera and shading defaults of scene.toml's dragon section —
+1920x1080, path tracing, 4 bounces (max_depth 5), 1 spp per step.
+At N > 1 the frame grows with N (same view, N x the pixels: 4 GPUs = 3840x2160) and is cut into
+64x64 tiles dealt round-robin over ranks; no communication per sample; one RCCL all_gather of the
+finished uchar4 tiles inside the timed region ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+SEED = 1
+MAX_DEPTH = 5  # primary segment + 4 bounces
+
+
+def cpu_baseline_and_work(scene_mod, oracle, sc, params, width, height, time_seed):
+    """rank 0, N = 1 only: (a) the CPU restatement timed on a bounded sample of the same frame
+    (reference-order traversal, all host threads we are allowed), (b) the algorithmic work per
+    ray from its ordered, distance-culled traversal of the same rays."""
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    threads = max(1, min(threads, len(os.sched_getaffinity(0)), 64))
+    oracle.set_threads(threads)
+    # calibrate on 1/16 of the rows, then size the timed sample for ~12 s of CPU work
+    cal = np.zeros(8, np.uint64)
+    t0 = time.perf_counter()
+    oracle.kernel_raytrace(sc, params, time_seed, width, height, max_depth=MAX_DEPTH, bands=(4, 16),
+                           counters=cal)
+    cal_dt = max(time.perf_counter() - t0, 1e-3)
+    spp = int(np.clip(round(12.0 / (cal_dt * 16.0)), 1, 64))
+    cnt = np.zeros(8, np.uint64)
+    t0 = time.perf_counter()
+    for s in range(spp):
+        oracle.kernel_raytrace(sc, params, time_seed + s, width, height, max_depth=MAX_DEPTH, counters=cnt)
+    dt = time.perf_counter() - t0
+    rays = int(cnt[0] + cnt[1] + cnt[2])
+    work = np.zeros(8, np.uint64)
+    oracle.kernel_raytrace(sc, params, time_seed, width, height, max_depth=MAX_DEPTH,
+                           ordered=True, count_work=True, counters=work)
+    wr = int(work[0] + work[1] + work[2])
+    n_node = float(work[4]) / wr
+    n_tri = float(work[5]) / wr
+    base = {
+        "value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{spp} spp of the whole {width}x{height} frame, max_depth {MAX_DEPTH}: {rays} rays in "
+                  f"{dt:.2f} s, reference-order traversal (kernels/raytrace.hpp:38-102), OpenMP",
+    }
+    return base, n_node, n_tri
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=660, help="stand-in mesh resolution (2*grid^2 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from nova_amd import capi, scene as S, tiles
+    from nova_amd.raytracer import Raytracer
+
+    capi.init(local_rank)  # fails loudly without the HIP library / a device
+    width, height = tiles.weak_scaling_dims(world)
+    if args.width and args.height:
+        width, height = args.width, args.height
+
+    sc = S.dragon_standin(args.grid, args.grid)
+    cam = S.Camera(width=width, height=height, **S.DRAGON_CAMERA)
+    params = S.make_scene_params(cam, shading_diffuse=(1.0, 1.0, 1.0), shading_metallic=0.4,
+                                 shading_roughness=0.1, path_tracing=True, num_samples=args.steps)
+    rt = Raytracer(local_rank)
+    rt.set_scene(sc, params, width, height)
+    capi.set_option(capi.OPT_MAX_DEPTH, MAX_DEPTH)
+    capi.set_option(capi.OPT_TILE_RANK, rank)
+    capi.set_option(capi.OPT_TILE_RANKS, world)
+    rt.start()
+
+    def barrier():
+        capi.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rt.raytrace(rt.step_time(SEED), read_back=False)
+    if dist is not None:  # warm the collective too
+        tiles.gather_frame(tiles.image_as_tensor(rt.color_img, torch.device("cuda", local_rank)),
+                           width, height, rank, world)
+    rt.start()
+    capi.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rt.raytrace(rt.step_time(SEED), read_back=False)
+    frame = None
+    if dist is not None:
+        frame = tiles.gather_frame(tiles.image_as_tensor(rt.color_img, torch.device("cuda", local_rank)),
+                                   width, height, rank, world)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    k = capi.counters()
+    local = np.array([k["rays_primary"], k["rays_bounce"], k["rays_shadow"], k["traverse_launches"]], np.float64)
+    trav_ms = k["traverse_ms"]
+    shade_ms = k["shade_ms"]
+    if dist is not None:
+        tt = torch.tensor([dt, trav_ms, shade_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, trav_ms, shade_ms = (float(x) for x in tt.cpu())
+        cc = torch.tensor(local, dtype=torch.float64, device="cuda")
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        total = cc.cpu().numpy()
+    else:
+        total = local
+    rays_primary, rays_bounce, rays_shadow = (int(x) for x in total[:3])
+    rays = rays_primary + rays_bounce + rays_shadow
+    rays_local = int(local[0] + local[1] + local[2])
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary + incoherent bounce)",
+            "value": round(rays / dt / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"dragon stand-in (displaced torus knot, {sc.triangles.shape[0]} triangles incl. "
+                            f"ground+light, BVH {sc.bvh.shape[0]} nodes), {width}x{height}, path tracing, "
+                            f"max_depth {MAX_DEPTH} (4 bounces), 1 spp per step, fixed seed {SEED}+sample",
+                "frame": [width, height],
+                "tiles": "64x64 round-robin over ranks" if world > 1 else "single GPU",
+                "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step",
+            },
+            "rays_per_step": rays // args.steps,
+            "mrays_per_s_primary": round(rays_primary / dt / 1e6, 2),
+            "mrays_per_s_incoherent": round((rays_bounce + rays_shadow) / dt / 1e6, 2),
+            "mrays_per_s_per_gpu": round(rays / dt / 1e6 / world, 2),
+            "ms_per_frame": round(dt / args.steps * 1e3, 4),
+            "traverse_ms_per_step": round(trav_ms / args.steps, 4),
+            "shade_ms_per_step": round(shade_ms / args.steps, 4),
+            "device": capi.device_name(),
+        }
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel": "k_traverse"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import bind as O  # checker / reported baseline only; never the measured path
+            base, n_node, n_tri = cpu_baseline_and_work(S, O, sc, params, width, height, SEED)
+            out["cpu_baseline"] = base
+            bytes_per_ray = 32.0 * n_node + 48.0 * n_tri + 64.0
+            launches = max(1, int(local[3]))
+            avg_launch_s = k["traverse_ms"] / launches / 1e3
+            bytes_per_launch = bytes_per_ray * rays_local / launches
+            achieved = bytes_per_launch / avg_launch_s / 1e9
+            roof.update({
+                "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
+                "n_node_per_ray": round(n_node, 2), "n_tri_per_ray": round(n_tri, 2),
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
+                "valu_ops_per_ray": round(17.0 * n_node + 33.0 * n_tri, 1),
+            })
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        else:
+            out["cpu_baseline"] = None
+        out["roofline"] = roof
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

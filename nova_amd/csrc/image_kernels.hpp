@@ -3,9 +3,10 @@
 // kernels/transforms.hpp:14-30).  Images are linear float4 / uchar4 buffers; one 16-byte access
 // per lane, consecutive lanes on consecutive texels (1 KiB per wave instruction).
 //
-// The reference reads its inputs through a LINEAR sampler at texel centres; that returns the
-// texel itself (bilinear weight 1 up to one ulp), so accumulate and the no-FXAA path fetch the
-// texel directly.  FXAA's half-texel and fractional taps go through the software sampler.
+// The reference reads every input through a LINEAR, CLAMP sampler at the pixel centre
+// (kernels.cu:59-64,103-110).  That is the texel itself except where (x+0.5)/W*W rounds off x+0.5
+// and where a neighbouring texel is NaN/inf (NaN * 0 = NaN), so the same software sampler is used
+// here: the three extra taps hit the lines the neighbouring lanes fetch anyway.
 #pragma once
 
 #include "shade.hpp"
@@ -17,23 +18,29 @@ struct AccumulateArgs {
   uint32_t denoise;
   const float4 *color1, *albedo1, *normal1, *prev_color, *prev_albedo, *prev_normal;
   float4 *color2, *albedo2, *normal2;
-  uint32_t n_pixels;
+  uint32_t width, height;
 };
 
 __global__ __launch_bounds__(256) void k_accumulate(AccumulateArgs A) {
   const float si = static_cast<float>(A.sample_index), si1 = static_cast<float>(A.sample_index + 1);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n_pixels; i += gridDim.x * blockDim.x) {
-    V3 c = xyz(A.color1[i]);
+  const uint32_t n_pixels = A.width * A.height;
+  const int w = static_cast<int>(A.width), h = static_cast<int>(A.height);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
+    const uint32_t y = i / A.width, x = i - y * A.width;
+    const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
+    const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
+    auto ld = [&](const float4* p) { return sample_linear<false>(ImageView { p, w, h, 1 }, u, v, 0); };
+    V3 c = ld(A.color1);
     V3 a { 0.f, 0.f, 0.f }, n { 0.f, 0.f, 0.f };
     if (A.denoise) {
-      a = xyz(A.albedo1[i]);
-      n = xyz(A.normal1[i]);
+      a = ld(A.albedo1);
+      n = ld(A.normal1);
     }
     if (A.sample_index != 0) {
-      c = fma3(xyz(A.prev_color[i]), si, c) / si1;
+      c = fma3(ld(A.prev_color), si, c) / si1;
       if (A.denoise) {
-        a = fma3(xyz(A.prev_albedo[i]), si, a) / si1;
-        n = normalize(fma3(xyz(A.prev_normal[i]), si, n) / si1);
+        a = fma3(ld(A.prev_albedo), si, a) / si1;
+        n = normalize(fma3(ld(A.prev_normal), si, n) / si1);
       }
     }
     A.color2[i] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -135,13 +142,13 @@ __global__ __launch_bounds__(256) void k_post_process(PostArgs A) {
   const float inv_w = 1.0f / static_cast<float>(A.width), inv_h = 1.0f / static_cast<float>(A.height);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     V3 c;
+    const uint32_t y = i / A.width, x = i - y * A.width;
+    const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
+    const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
     if (A.anti_aliasing) {
-      const uint32_t y = i / A.width, x = i - y * A.width;
-      const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
-      const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
       c = fxaa(A.color2, inv_w, inv_h, u, v);
     } else {
-      c = xyz(A.color2.texels[i]);
+      c = sample_linear<false>(A.color2, u, v, 0);
     }
     // tone_map, gamma_correct, float3_to_uchar3 (kernels/transforms.hpp:14-26)
     const float g = 1.0f / 2.2f;

@@ -65,6 +65,8 @@ struct FrameBuffers {
   float4* ray_o[2] = {};
   float4* ray_d[2] = {};
   float4* hits = nullptr;
+  unsigned long long* block_counters = nullptr; // [capacity / kShadeBlock][4]
+  uint32_t n_blocks = 0;
 };
 
 struct Ctx {
@@ -88,6 +90,8 @@ struct Ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_traverse, ev_shade;
   double traverse_ms = 0, shade_ms = 0;
   uint64_t traverse_launches = 0;
+  uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
+  uint64_t folded[4] = { 0, 0, 0, 0 }; // block counters of released frame buffers
 };
 
 Ctx g;
@@ -355,6 +359,29 @@ template <int STACK>
 int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
   const int blocks_per_cu = STACK <= 32 ? 4 : 2;
   dim3 grid(static_cast<unsigned>(g.num_cus * blocks_per_cu)), block(256);
+  // opt_kernel: 0 = batch kernel (64 rays per wave per batch; production: fastest measured, see
+  // DESIGN.md "Experiments"); 1..5 = per-lane refill variants kept for A/B runs:
+  // 1 = if-if, refill at >= 24 idle lanes; 2 = while-while; 3..5 = other thresholds
+#define NOVA_LAUNCH_WW(WWF, RMIN)                                                                              \
+  do {                                                                                                         \
+    if (cull) {                                                                                                \
+      if (count) hipLaunchKernelGGL((k_traverse_ww<STACK, true, true, WWF, RMIN>), grid, block, 0, g.stream, A);   \
+      else hipLaunchKernelGGL((k_traverse_ww<STACK, true, false, WWF, RMIN>), grid, block, 0, g.stream, A);        \
+    } else {                                                                                                   \
+      if (count) hipLaunchKernelGGL((k_traverse_ww<STACK, false, true, WWF, RMIN>), grid, block, 0, g.stream, A);  \
+      else hipLaunchKernelGGL((k_traverse_ww<STACK, false, false, WWF, RMIN>), grid, block, 0, g.stream, A);       \
+    }                                                                                                          \
+    return static_cast<int>(hipGetLastError());                                                                \
+  } while (0)
+  switch (g.opt_kernel) {
+    case 1: NOVA_LAUNCH_WW(false, 24);
+    case 2: NOVA_LAUNCH_WW(true, 24);
+    case 3: NOVA_LAUNCH_WW(false, 8);
+    case 4: NOVA_LAUNCH_WW(false, 40);
+    case 5: NOVA_LAUNCH_WW(true, 40);
+    default: break;
+  }
+#undef NOVA_LAUNCH_WW
   if (cull) {
     if (count) hipLaunchKernelGGL((k_traverse<STACK, true, true>), grid, block, 0, g.stream, A);
     else hipLaunchKernelGGL((k_traverse<STACK, true, false>), grid, block, 0, g.stream, A);
@@ -392,8 +419,18 @@ int ensure_frame_buffers(uint32_t paths) {
       (void) hipFree(fb.ray_d[s]); fb.ray_d[s] = nullptr;
     }
     (void) hipFree(fb.hits); fb.hits = nullptr;
+    (void) hipFree(fb.block_counters); fb.block_counters = nullptr;
     fb.capacity = 0;
+    fb.n_blocks = 0;
   };
+  // counts accumulated so far live in the old per-block slots: fold them into the totals first
+  if (fb.block_counters) {
+    std::vector<unsigned long long> hb(4 * static_cast<size_t>(fb.n_blocks));
+    if (hipMemcpy(hb.data(), fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (size_t b = 0; b < fb.n_blocks; b++)
+        for (int q = 0; q < 4; q++) g.folded[q] += hb[4 * b + q];
+    }
+  }
   release();
   const size_t plane = static_cast<size_t>(paths) * sizeof(float4);
   for (int s = 0; s < 2; s++) {
@@ -406,6 +443,10 @@ int ensure_frame_buffers(uint32_t paths) {
     if (e != hipSuccess) { release(); return static_cast<int>(e); }
   }
   hipError_t e = hipMalloc(&fb.hits, 3 * plane);
+  if (e != hipSuccess) { release(); return static_cast<int>(e); }
+  fb.n_blocks = (paths + kShadeBlock - 1) / kShadeBlock;
+  e = hipMalloc(&fb.block_counters, 4 * static_cast<size_t>(fb.n_blocks) * 8);
+  if (e == hipSuccess) e = hipMemset(fb.block_counters, 0, 4 * static_cast<size_t>(fb.n_blocks) * 8);
   if (e != hipSuccess) { release(); return static_cast<int>(e); }
   fb.capacity = paths;
   return 0;
@@ -672,12 +713,19 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   collect_events();
   unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  uint64_t bc[4] = { g.folded[0], g.folded[1], g.folded[2], g.folded[3] };
+  if (g.fb.block_counters) {
+    std::vector<unsigned long long> hb(4 * static_cast<size_t>(g.fb.n_blocks));
+    HIP_TRY(hipMemcpy(hb.data(), g.fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < g.fb.n_blocks; b++)
+      for (int q = 0; q < 4; q++) bc[q] += hb[4 * b + q];
+  }
   out->node_visits = h[0];
   out->triangle_tests = h[1];
-  out->rays_primary = h[2];
-  out->rays_bounce = h[3];
-  out->rays_shadow = h[4];
-  out->path_segments = h[5];
+  out->rays_primary = g.host_primary;
+  out->rays_bounce = bc[0] + bc[1];
+  out->rays_shadow = bc[2];
+  out->path_segments = bc[3];
   out->traverse_ms = g.traverse_ms;
   out->shade_ms = g.shade_ms;
   out->traverse_launches = g.traverse_launches;
@@ -690,6 +738,9 @@ int nova_hip_reset_counters(void) {
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+  if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, 4 * static_cast<size_t>(g.fb.n_blocks) * 8));
+  for (auto& f : g.folded) f = 0;
+  g.host_primary = 0;
   g.traverse_ms = g.shade_ms = 0;
   g.traverse_launches = 0;
   return 0;
@@ -758,11 +809,18 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   F.stride = P;
   F.max_depth = static_cast<uint32_t>(g.opt_max_depth);
   F.n_active = g.d_queues;
-  F.counters = g.d_counters;
+  F.block_counters = g.fb.block_counters;
   uint32_t* queue_heads = g.d_queues + (kMaxIterations + 2);
 
   HIP_TRY(hipMemsetAsync(g.d_queues, 0, 2 * (kMaxIterations + 2) * sizeof(uint32_t), g.stream));
   const unsigned blocks = (P + 255) / 256;
+  const unsigned shade_blocks = (P + kShadeBlock - 1) / kShadeBlock;
+  // primary rays = valid pixels of this rank's tiles
+  for (uint32_t t = rank; t < n_tiles; t += ranks) {
+    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+    const uint32_t w = std::min(kTileSize, width - tx * kTileSize), hgt = std::min(kTileSize, height - ty * kTileSize);
+    g.host_primary += static_cast<uint64_t>(w) * hgt;
+  }
   {
     hipEvent_t e0 = next_event(), e1 = next_event();
     if (e0) (void) hipEventRecord(e0, g.stream);
@@ -795,7 +853,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     {
       hipEvent_t e0 = next_event(), e1 = next_event();
       if (e0) (void) hipEventRecord(e0, g.stream);
-      hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, g.stream, F, it, planes_of(in), planes_of(out),
+      hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(kShadeBlock), 0, g.stream, F, it, planes_of(in), planes_of(out),
                          g.fb.ray_o[in], g.fb.ray_d[in], g.fb.hits, g.fb.ray_o[out], g.fb.ray_d[out]);
       if (e1) (void) hipEventRecord(e1, g.stream);
       if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
@@ -846,8 +904,9 @@ int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
   A.color2 = ptr(temp_color2);
   A.albedo2 = ptr(albedo_feature2);
   A.normal2 = ptr(normal_feature2);
-  A.n_pixels = width * height;
-  const unsigned blocks = std::min<unsigned>((A.n_pixels + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+  A.width = width;
+  A.height = height;
+  const unsigned blocks = std::min<unsigned>((width * height + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, g.stream, A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g.stream));

@@ -54,8 +54,10 @@ struct FrameArgs {
   uint32_t stride;    // P: ray slot of kind k for path j is k * stride + j
   uint32_t max_depth; // 0 = unbounded
   uint32_t* n_active; // n_active[it] = paths entering pass `it`
-  unsigned long long* counters; // [2] primary [3] bounce [4] shadow [5] segments
+  unsigned long long* block_counters; // [block][4]: bounce, MIS, shadow rays, shaded segments
 };
+
+constexpr uint32_t kShadeBlock = 1024; // one compaction atomic per 1024 paths
 
 // ---- software image sampling (CDNA has no sampler): OpenCL 1.2 §8.2 linear filter, normalised
 // coordinates; repeat = CLK_ADDRESS_REPEAT, else CLK_ADDRESS_CLAMP (border colour 0), which is
@@ -92,9 +94,10 @@ NV_DEV V3 sample_linear(const ImageView& im, float s, float t, int layer) {
   const float4 t00 = texel(im, i0, j0, layer), t10 = texel(im, i1, j0, layer);
   const float4 t01 = texel(im, i0, j1, layer), t11 = texel(im, i1, j1, layer);
   const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-  return { t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
-           t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
-           t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11 };
+  // ((T00 w00 + T10 w10) + T01 w01) + T11 w11 with the fusion of the numeric contract
+  return { fma_(t11.x, w11, fma_(t01.x, w01, fma_(t00.x, w00, t10.x * w10))),
+           fma_(t11.y, w11, fma_(t01.y, w01, fma_(t00.y, w00, t10.y * w10))),
+           fma_(t11.z, w11, fma_(t01.z, w01, fma_(t00.z, w00, t10.z * w10))) };
 }
 
 NV_DEV V3 v3(const nova_float3& v) { return { v.x, v.y, v.z }; }
@@ -259,11 +262,6 @@ NV_DEV bool path_pixel(const FrameArgs& F, uint32_t p, uint32_t& x, uint32_t& y)
   return x < F.width && y < F.height;
 }
 
-NV_DEV void wave_count(unsigned long long* counter, bool pred) {
-  const uint64_t m = __ballot(pred);
-  if (m != 0 && rank_in_mask(m) == 0 && pred) atomicAdd(counter, static_cast<unsigned long long>(__popcll(m)));
-}
-
 // Stage 1: camera rays.  kernels/kernels.cu:23-27 (seed) and kernels/raytrace.hpp:117-127.
 __global__ __launch_bounds__(256) void k_generate(FrameArgs F, PathPlanes S, float4* ray_o, float4* ray_d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,8 +269,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameArgs F, PathPlanes S, flo
   if (p == 0) F.n_active[0] = total;
   if (p >= total) return;
   uint32_t x, y;
-  const bool valid = path_pixel(F, p, x, y);
-  if (!valid) {
+  if (!path_pixel(F, p, x, y)) {
     S.b[p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(kEmptyPixel));
     ray_o[p] = make_float4(0.f, 0.f, 0.f, -1.0f);
     ray_d[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -291,11 +288,10 @@ __global__ __launch_bounds__(256) void k_generate(FrameArgs F, PathPlanes S, flo
     ray_o[p] = make_float4(E.eye_pos.x, E.eye_pos.y, E.eye_pos.z, kFltMax);
     ray_d[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(0u));
   }
-  wave_count(&F.counters[2], valid);
 }
 
 // Stage 3: resolve the previous segment's direct lighting, shade the new hit, emit rays.
-__global__ __launch_bounds__(256) void k_shade(FrameArgs F, uint32_t it, PathPlanes I, PathPlanes O,
+__global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it, PathPlanes I, PathPlanes O,
                                                const float4* ray_o_in, const float4* ray_d_in,
                                                const float4* hits, float4* ray_o_out, float4* ray_d_out) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -465,38 +461,57 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs F, uint32_t it, PathPla
     }
   }
 
-  // compaction: one atomic per wave
+  // compaction: one atomic per block (same-address atomics serialise at ~12 ns each, so one per
+  // wave would cost more than the shading itself); ray/segment counts go to per-block slots
+  // with plain stores, summed on the host when counters are read.
+  __shared__ uint32_t s_alive[kShadeBlock / 64];
+  __shared__ uint32_t s_count[4][kShadeBlock / 64];
+  __shared__ uint32_t s_base;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint64_t mask = __ballot(alive);
-  if (mask != 0) {
-    const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(mask));
-    uint32_t base = 0;
-    if (lane_id() == leader) base = atomicAdd(&F.n_active[it + 1], static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, leader);
-    if (alive) {
-      const uint32_t s = base + rank_in_mask(mask);
-      O.a[s] = make_float4(color.x, color.y, color.z, __uint_as_float(rng));
-      O.b[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
-      O.c[s] = make_float4(thr_before.x, thr_before.y, thr_before.z, __uint_as_float(out_flags));
-      if (out_flags & kFlagPending) {
-        O.d[s] = make_float4(nee_term.x, nee_term.y, nee_term.z, mis_ndl);
-        O.e[s] = make_float4(mis_f.x, mis_f.y, mis_f.z, __int_as_float(here_light));
-        O.f[s] = make_float4(mis_pdf.x, mis_pdf.y, mis_pdf.z, 0.0f);
-      }
-      ray_o_out[s] = make_float4(point.x, point.y, point.z, emit_cont ? kFltMax : -1.0f);
-      ray_d_out[s] = make_float4(cont_dir.x, cont_dir.y, cont_dir.z, __uint_as_float(0u));
-      if (F.num_lights > 0) {
-        const size_t s1 = static_cast<size_t>(P) + s, s2 = 2 * static_cast<size_t>(P) + s;
-        ray_o_out[s1] = make_float4(point.x, point.y, point.z, emit_shadow ? shadow_tmax : -1.0f);
-        ray_d_out[s1] = make_float4(shadow_dir.x, shadow_dir.y, shadow_dir.z, __uint_as_float(1u));
-        ray_o_out[s2] = make_float4(point.x, point.y, point.z, emit_mis ? kFltMax : -1.0f);
-        ray_d_out[s2] = make_float4(mis_dir.x, mis_dir.y, mis_dir.z, __uint_as_float(0u));
-      }
+  const uint64_t m_cont = __ballot(alive && emit_cont), m_mis = __ballot(alive && emit_mis),
+                 m_shadow = __ballot(alive && emit_shadow), m_shaded = __ballot(shaded);
+  if (lane == 0) {
+    s_alive[wave] = static_cast<uint32_t>(__popcll(mask));
+    s_count[0][wave] = static_cast<uint32_t>(__popcll(m_cont));
+    s_count[1][wave] = static_cast<uint32_t>(__popcll(m_mis));
+    s_count[2][wave] = static_cast<uint32_t>(__popcll(m_shadow));
+    s_count[3][wave] = static_cast<uint32_t>(__popcll(m_shaded));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0, c[4] = { 0, 0, 0, 0 };
+    for (uint32_t w = 0; w < kShadeBlock / 64; w++) {
+      total += s_alive[w];
+      for (int q = 0; q < 4; q++) c[q] += s_count[q][w];
+    }
+    s_base = total ? atomicAdd(&F.n_active[it + 1], total) : 0u;
+    unsigned long long* bc = F.block_counters + 4 * static_cast<size_t>(blockIdx.x);
+    for (int q = 0; q < 4; q++)
+      if (c[q]) bc[q] += c[q];
+  }
+  __syncthreads();
+  if (alive) {
+    uint32_t s = s_base + rank_in_mask(mask);
+    for (uint32_t w = 0; w < wave; w++) s += s_alive[w];
+    O.a[s] = make_float4(color.x, color.y, color.z, __uint_as_float(rng));
+    O.b[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
+    O.c[s] = make_float4(thr_before.x, thr_before.y, thr_before.z, __uint_as_float(out_flags));
+    if (out_flags & kFlagPending) {
+      O.d[s] = make_float4(nee_term.x, nee_term.y, nee_term.z, mis_ndl);
+      O.e[s] = make_float4(mis_f.x, mis_f.y, mis_f.z, __int_as_float(here_light));
+      O.f[s] = make_float4(mis_pdf.x, mis_pdf.y, mis_pdf.z, 0.0f);
+    }
+    ray_o_out[s] = make_float4(point.x, point.y, point.z, emit_cont ? kFltMax : -1.0f);
+    ray_d_out[s] = make_float4(cont_dir.x, cont_dir.y, cont_dir.z, __uint_as_float(0u));
+    if (F.num_lights > 0) {
+      const size_t s1 = static_cast<size_t>(P) + s, s2 = 2 * static_cast<size_t>(P) + s;
+      ray_o_out[s1] = make_float4(point.x, point.y, point.z, emit_shadow ? shadow_tmax : -1.0f);
+      ray_d_out[s1] = make_float4(shadow_dir.x, shadow_dir.y, shadow_dir.z, __uint_as_float(1u));
+      ray_o_out[s2] = make_float4(point.x, point.y, point.z, emit_mis ? kFltMax : -1.0f);
+      ray_d_out[s2] = make_float4(mis_dir.x, mis_dir.y, mis_dir.z, __uint_as_float(0u));
     }
   }
-  wave_count(&F.counters[3], (alive && emit_cont));
-  wave_count(&F.counters[3], (alive && emit_mis));
-  wave_count(&F.counters[4], (alive && emit_shadow && !(shadow_tmax < 0.0f)));
-  wave_count(&F.counters[5], shaded);
 }
 
 }

@@ -1,0 +1,111 @@
+"""Image-tile partition of a frame across the GPUs of a node, and the final gather.
+
+The reference renders on one device only.  Pixels are independent — the RNG stream
+depends only on (x, y, W, time) (reference ``kernels/kernels.cu:27``) and the scene is read-only —
+so the frame is cut into 64x64 tiles dealt round-robin over ranks (``tile_id % ranks == rank``,
+the rule ``NOVA_HIP_OPT_TILE_RANK/RANKS`` implements inside ``kernel_raytrace``), with the scene
+replicated per GPU and NO communication per sample.  Once per displayed/final frame the finished
+tiles are gathered to rank 0 with one collective (RCCL all_gather over equal-sized tile stacks;
+every peer has its own xGMI link to the root, so this is one hop).
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU
+tests).  Results are bit-identical to a single-GPU render of the same frame.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+TILE = 64
+
+
+def tile_grid(width: int, height: int) -> Tuple[int, int]:
+    return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+
+
+def tiles_of_rank(width: int, height: int, rank: int, ranks: int) -> List[int]:
+    tx, ty = tile_grid(width, height)
+    return list(range(rank, tx * ty, ranks))
+
+
+def max_tiles_per_rank(width: int, height: int, ranks: int) -> int:
+    tx, ty = tile_grid(width, height)
+    return (tx * ty + ranks - 1) // ranks
+
+
+def pack_tiles(frame, width: int, height: int, rank: int, ranks: int):
+    """frame: torch tensor [H, W, C] -> [max_tiles_per_rank, 64, 64, C] holding this rank's tiles
+    in tile-id order (zero padded at the image border and at the end of the stack)."""
+    import torch
+
+    tx, ty = tile_grid(width, height)
+    c = frame.shape[-1]
+    padded = torch.zeros((ty * TILE, tx * TILE, c), dtype=frame.dtype, device=frame.device)
+    padded[:height, :width] = frame
+    tiles = padded.view(ty, TILE, tx, TILE, c).permute(0, 2, 1, 3, 4).reshape(tx * ty, TILE, TILE, c)
+    mine = torch.as_tensor(tiles_of_rank(width, height, rank, ranks), device=frame.device, dtype=torch.long)
+    out = torch.zeros((max_tiles_per_rank(width, height, ranks), TILE, TILE, c), dtype=frame.dtype,
+                      device=frame.device)
+    out[: mine.numel()] = tiles[mine]
+    return out
+
+
+def unpack_tiles(stacks, width: int, height: int, ranks: int):
+    """stacks: [ranks, max_tiles_per_rank, 64, 64, C] -> frame [H, W, C]."""
+    import torch
+
+    tx, ty = tile_grid(width, height)
+    c = stacks.shape[-1]
+    tiles = torch.zeros((tx * ty, TILE, TILE, c), dtype=stacks.dtype, device=stacks.device)
+    for r in range(ranks):
+        ids = tiles_of_rank(width, height, r, ranks)
+        if ids:
+            tiles[torch.as_tensor(ids, device=stacks.device)] = stacks[r, : len(ids)]
+    frame = tiles.view(ty, tx, TILE, TILE, c).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, c)
+    return frame[:height, :width].contiguous()
+
+
+def gather_frame(local_frame, width: int, height: int, rank: int, ranks: int, group=None):
+    """All ranks call this with their locally rendered frame (only their own tiles need to be
+    valid).  Returns the assembled frame on rank 0 and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    mine = pack_tiles(local_frame, width, height, rank, ranks)
+    if ranks == 1:
+        return unpack_tiles(mine.unsqueeze(0), width, height, 1)
+    gathered = torch.empty((ranks * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                           device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)  # rank r's stack lands at [r*n, (r+1)*n)
+    if rank != 0:
+        return None
+    return unpack_tiles(gathered.view((ranks,) + tuple(mine.shape)), width, height, ranks)
+
+
+class DeviceArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that torch can wrap the
+    backend's image memory without a copy (torch.as_tensor(DeviceArray(...), device='cuda'))."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def image_as_tensor(image, device):
+    """capi.Image -> torch tensor view [H, W, 4] (float32 or uint8) on `device`."""
+    import torch
+
+    typestr = "<f4" if image.texel_bytes == 16 else "|u1"
+    arr = DeviceArray(image.data_ptr, (image.height, image.width, 4), typestr)
+    return torch.as_tensor(arr, device=device)
+
+
+def weak_scaling_dims(n_gpus: int, base=(1920, 1080)) -> Tuple[int, int]:
+    """Frame size with n_gpus x the pixels of `base` at (nearly) the same aspect: 1 -> 1920x1080,
+    4 -> 3840x2160; widths are multiples of 64 so that tiles are whole."""
+    if n_gpus == 1:
+        return base
+    w = int(round(base[0] * np.sqrt(n_gpus) / 64.0)) * 64
+    h = int(round(w * base[1] / base[0]))
+    return w, h

@@ -42,7 +42,7 @@ def set_threads(n: int):
 
 
 def kernel_raytrace(scene, params, time, width, height, denoise_available=0, meta=None, sky=None,
-                    max_depth=0, ordered=False, count_work=False, rows=None, counters=None):
+                    max_depth=0, ordered=False, count_work=False, rows=None, bands=None, counters=None):
     """kernels/kernels.cu:9-40.  Returns (color, albedo, normal) float32[h, w, 4]; `counters`
     (uint64[8], optional) accumulates primary/bounce/shadow rays, segments, node visits, tri tests."""
     meta = scene.meta if meta is None else meta
@@ -53,6 +53,7 @@ def kernel_raytrace(scene, params, time, width, height, denoise_available=0, met
     mats = scene.materials
     params = np.ascontiguousarray(params)
     r0, r1 = (0, height) if rows is None else rows
+    band_rows, band_period = (0, 0) if bands is None else bands  # render 1 band of rows in `period`
     rc = lib().oracle_kernel_raytrace(
         _p(params), ctypes.c_uint32(time), _p(color), ctypes.c_uint32(width),
         ctypes.c_uint32(height), _p(scene.triangles), _p(meta), _p(scene.bvh),
@@ -62,7 +63,7 @@ def kernel_raytrace(scene, params, time, width, height, denoise_available=0, met
         ctypes.c_uint32(sky.shape[0]), ctypes.c_uint32(denoise_available), _p(albedo), _p(normal),
         ctypes.c_uint32(max_depth), ctypes.c_int(1 if ordered else 0),
         ctypes.c_int(1 if count_work else 0), ctypes.c_uint32(r0), ctypes.c_uint32(r1),
-        _p(counters))
+        ctypes.c_uint32(band_rows), ctypes.c_uint32(band_period), _p(counters))
     assert rc == 0
     return color, albedo, normal
 

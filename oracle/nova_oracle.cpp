@@ -363,9 +363,10 @@ f3 sample_linear(const Image& im, float s, float t, int layer, bool repeat) {
   f4 t00 = im.at(i0, j0, layer), t10 = im.at(i1, j0, layer), t01 = im.at(i0, j1, layer),
      t11 = im.at(i1, j1, layer);
   float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-  return { t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
-           t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
-           t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11 };
+  // ((T00 w00 + T10 w10) + T01 w01) + T11 w11, fused as clang fuses it (see the FP contract above)
+  return { fmaf(t11.x, w11, fmaf(t01.x, w01, fmaf(t00.x, w00, t10.x * w10))),
+           fmaf(t11.y, w11, fmaf(t01.y, w01, fmaf(t00.y, w00, t10.y * w10))),
+           fmaf(t11.z, w11, fmaf(t01.z, w01, fmaf(t00.z, w00, t10.z * w10))) };
 }
 
 // ---- shading helpers ---------------------------------------------------------------------------
@@ -787,7 +788,8 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
                            uint32_t mat_w, uint32_t mat_h, uint32_t mat_layers, const float* sky,
                            uint32_t sky_w, uint32_t sky_h, uint32_t denoise_available, float* albedo1,
                            float* normal1, uint32_t max_depth, int ordered, int count_work,
-                           uint32_t row_begin, uint32_t row_end, uint64_t* counters) {
+                           uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t band_period,
+                           uint64_t* counters) {
   SceneView S { tris, meta, bvh, lights, num_lights,
                 { materials, (int) mat_w, (int) mat_h, (int) mat_layers }, { sky, (int) sky_w, (int) sky_h, 1 } };
   uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
@@ -798,6 +800,8 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c0, c1, c2, c3, c4, c5) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
   for (int y = (int) row_begin; y < (int) row_end; y++) {
     RayCount rc;
+    // optional row sampling: bands of `band_rows` rows, one band in every `band_period`
+    if (band_period > 1 && band_rows > 0 && ((static_cast<uint32_t>(y) - row_begin) / band_rows) % band_period != 0) continue;
     for (int x = 0; x < (int) width; x++) {
       uint32_t rng = wang_hash(static_cast<uint32_t>(y) * width + static_cast<uint32_t>(x) + wang_hash(time));
       f3 albedo { 0, 0, 0 }, normal { 0, 0, 0 };
@@ -820,18 +824,24 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
   return 0;
 }
 
-// kernels/kernels.cu:42-92.  Images are read at texel centres (the linear sampler at a texel
-// centre returns that texel up to 1 ulp of blending weight).
+// kernels/kernels.cu:42-92.  Like the reference, every input is read through the LINEAR, CLAMP
+// sampler at the pixel's centre (kernels.cu:59-64, transforms.hpp:42-44): that is the texel itself
+// except where (x+0.5)/W*W rounds off x+0.5 (weights within 1e-7 of 1/0) and where a neighbour
+// holds NaN/inf (NaN * 0 = NaN: the renormalised zero normals of sky pixels spread, as they do in
+// the reference).
 int oracle_kernel_accumulate(int32_t sample_index, uint32_t denoise_available, const float* color1,
                              const float* albedo1, const float* normal1, const float* prev_color,
                              const float* prev_albedo, const float* prev_normal, float* color2,
                              float* albedo2, float* normal2, uint32_t width, uint32_t height) {
-  const size_t n = static_cast<size_t>(width) * height;
   const float si = static_cast<float>(sample_index), si1 = static_cast<float>(sample_index + 1);
 #pragma omp parallel for
-  for (int64_t i = 0; i < (int64_t) n; i++) {
-    auto ld = [&](const float* p) { return f3 { p[4 * i], p[4 * i + 1], p[4 * i + 2] }; };
-    auto st = [&](float* p, f3 v) { p[4 * i] = v.x; p[4 * i + 1] = v.y; p[4 * i + 2] = v.z; p[4 * i + 3] = 1.0f; };
+  for (int y = 0; y < (int) height; y++)
+  for (int x = 0; x < (int) width; x++) {
+    const size_t i = static_cast<size_t>(y) * width + x;
+    const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(width);
+    const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(height);
+    auto ld = [&](const float* p) { return sample_linear(Image { p, (int) width, (int) height, 1 }, u, v, 0, false); };
+    auto st = [&](float* p, f3 c3) { p[4 * i] = c3.x; p[4 * i + 1] = c3.y; p[4 * i + 2] = c3.z; p[4 * i + 3] = 1.0f; };
     f3 c = ld(color1);
     f3 a = denoise_available ? ld(albedo1) : f3 { 0, 0, 0 };
     f3 nn = denoise_available ? ld(normal1) : f3 { 0, 0, 0 };
@@ -860,13 +870,12 @@ int oracle_kernel_post_process(const nova_scene_params* params, const float* col
   for (int y = 0; y < (int) height; y++) {
     for (int x = 0; x < (int) width; x++) {
       f3 c;
+      float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(width);
+      float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(height);
       if (params->anti_aliasing) {
-        float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(width);
-        float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(height);
         c = fxaa(im, inv_w, inv_h, u, v);
       } else {
-        const float* p = color2 + 4 * (static_cast<size_t>(y) * width + x);
-        c = { p[0], p[1], p[2] };
+        c = sample_linear(im, u, v, 0, false);
       }
       f3 e = { nova_expf(-c.x * params->exposure), nova_expf(-c.y * params->exposure), nova_expf(-c.z * params->exposure) };
       f3 m = splat(1.0f) - e;

@@ -7,7 +7,7 @@ from nova_amd.raytracer import Raytracer
 from oracle import bind as O
 capi.init(0)
 t = time.time(); sc = S.dragon_standin(); print("scene build %.1fs" % (time.time() - t), sc.triangles.shape, flush=True)
-W, H = 960, 540
+W, H = 1920, 1080
 cam = S.Camera(width=W, height=H, **S.DRAGON_CAMERA)
 rt = Raytracer(0)
 p0 = S.make_scene_params(cam, path_tracing=False)
@@ -28,10 +28,12 @@ rt.set_meta(sc.meta); rt.sky_img.write(sc.sky)
 p = S.make_scene_params(cam, shading_metallic=0.4, shading_roughness=0.1)
 rt.params = p
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
-for mode in (0, 1):
+for mode, kern in ((0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (1, 0)):
     capi.set_option(capi.OPT_TRAVERSAL, mode)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, kern)
+    print("kernel", kern)
     rt.kernel_raytrace(3)
-    for cw in (0, 1):
+    for cw in (0,):
         capi.set_option(capi.OPT_COUNT_WORK, cw)
         capi.reset_counters()
         t = time.time(); rt.kernel_raytrace(3); dt = time.time() - t
@@ -41,8 +43,9 @@ for mode in (0, 1):
             mode, cw, dt * 1e3, k["traverse_ms"], k["shade_ms"], rays, rays / dt / 1e6, rays / k["traverse_ms"] / 1e3,
             k["node_visits"] / rays, k["triangle_tests"] / rays), flush=True)
     c = rt.temp_color_img1.read()
-    if mode == 0: c0 = c
-capi.set_option(capi.OPT_TRAVERSAL, 0); capi.set_option(capi.OPT_COUNT_WORK, 0)
+    if mode == 0 and kern == 0: c0 = c
+    if mode == 0 and kern >= 1: print('ww vs batch kernel bit-equal:', bool((c0 == c).all()))
+capi.set_option(capi.OPT_TRAVERSAL, 0); capi.set_option(capi.OPT_COUNT_WORK, 0); capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
 print("culled vs walk radiance bit-equal:", bool((c0 == c).all()), flush=True)
 t = time.time(); co = O.kernel_raytrace(sc, p, 3, W, H, max_depth=5)[0]; print("oracle %.1fs" % (time.time() - t))
 d = c0[..., :3].astype(np.float64) - co[..., :3]

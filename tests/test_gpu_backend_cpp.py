@@ -1,0 +1,51 @@
+"""GPU (-m gpu): the C++ drop-in backend (nova_amd/backend/hip: nova::Accelerator, Buffer, Image2D*,
+kernel entry points) driven with the statements of Raytracer::raytrace by its self-test binary;
+results compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nova_amd import scene as S
+from tests.conftest import rel_rmse
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "nova_amd", "backend", "hip", "selftest")
+
+
+@pytest.mark.parametrize("denoise", [0, 1])
+def test_cpp_accelerator_runs_the_reference_schedule(tmp_path, cornell, denoise):
+    from oracle import bind as O
+    assert os.path.exists(EXE), "build the backend self-test first (__graft_entry__.build())"
+    w, h, samples, seed = 96, 64, 3, 7
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.CORNELL_CAMERA))
+    d = str(tmp_path)
+    np.ascontiguousarray(p).tofile(os.path.join(d, "params.bin"))
+    cornell.triangles.tofile(os.path.join(d, "tris.bin"))
+    cornell.meta.tofile(os.path.join(d, "meta.bin"))
+    cornell.bvh.tofile(os.path.join(d, "bvh.bin"))
+    cornell.lights.tofile(os.path.join(d, "lights.bin"))
+    m, sky = cornell.materials, cornell.sky
+    np.array([m.shape[2], m.shape[1], m.shape[0], sky.shape[1], sky.shape[0]], np.uint32).tofile(
+        os.path.join(d, "image_dims.bin"))
+    m.tofile(os.path.join(d, "materials.bin"))
+    sky.tofile(os.path.join(d, "sky.bin"))
+    env = dict(os.environ, NOVA_HIP_MAX_DEPTH="4")
+    r = subprocess.run([EXE, d, str(w), str(h), str(samples), str(seed), str(denoise)], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "selftest OK" in r.stdout
+
+    prev = [np.zeros((h, w, 4), np.float32) for _ in range(3)]
+    for s in range(samples):
+        c = O.kernel_raytrace(cornell, p, seed + s, w, h, denoise_available=denoise, max_depth=4)
+        prev = list(O.kernel_accumulate(s, denoise, *c, *prev))
+    pixels = np.fromfile(os.path.join(d, "out_pixels.bin"), np.uint8).reshape(h, w, 4)
+    color = np.fromfile(os.path.join(d, "out_color.bin"), np.float32).reshape(h, w, 4)
+    assert rel_rmse(color, prev[0]) <= 1e-3
+    assert (pixels == O.kernel_post_process(p, prev[0])).all()
+    if denoise:
+        albedo = np.fromfile(os.path.join(d, "out_albedo.bin"), np.float32).reshape(h, w, 4)
+        assert rel_rmse(albedo, prev[1]) <= 1e-3

@@ -1,0 +1,300 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (nova_amd.capi -> libnova_hip.so), against
+  * the golden vectors the reference itself produced (tests/golden/*.npz),
+  * the CPU oracle on seeded inputs,
+  * and, at BASELINE.json's full sizes, size-independent properties: the production (ordered,
+    culled) traversal must equal the reference walk (fixed order, no culling) ray for ray.
+Bar: triangle ids, hit records and bytes bit-exact; radiance rel-RMSE <= 1e-3 (north_star) — in
+practice 0: host and device share one arithmetic contract (DESIGN.md "Numerics")."""
+import numpy as np
+import pytest
+
+from nova_amd import capi, scene as S
+from nova_amd.raytracer import Raytracer
+from tests.conftest import random_rays, rel_rmse
+from tests.helpers import SOUP_CAMERA, check_scene, golden, id_inputs
+
+pytestmark = pytest.mark.gpu
+RADIANCE_TOL = 1e-3  # north_star: accumulated radiance within relative RMSE 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    capi.init(0)
+    yield
+    for opt in (capi.OPT_MAX_DEPTH, capi.OPT_TRAVERSAL, capi.OPT_COUNT_WORK, capi.OPT_TILE_RANK,
+                capi.OPT_TRAVERSE_KERNEL):
+        capi.set_option(opt, 0)
+    capi.set_option(capi.OPT_TILE_RANKS, 1)
+
+
+def oracle():
+    from oracle import bind as O
+    return O
+
+
+def gpu_primary_ids(sc, cam_kw, w, h, time, traversal=0, kernel=0):
+    p = S.make_scene_params(S.Camera(width=w, height=h, **cam_kw), path_tracing=False)
+    rt = Raytracer(0)
+    rt.set_scene(sc, p, w, h)
+    meta, sky = id_inputs(sc)
+    rt.set_meta(meta)
+    rt.sky_img.write(sky)
+    capi.set_option(capi.OPT_TRAVERSAL, traversal)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, kernel)
+    rt.kernel_raytrace(time)
+    capi.set_option(capi.OPT_TRAVERSAL, 0)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
+    return S.decode_ids(rt.temp_color_img1.read()).reshape(h, w)
+
+
+@pytest.mark.parametrize("fixture,file,cam,size", [
+    ("cornell", "ids_cornell_512.npz", S.CORNELL_CAMERA, 512),
+    ("soup50k", "ids_soup_256.npz", SOUP_CAMERA, 256),
+    ("knot_small", "ids_knot_256.npz", S.DRAGON_CAMERA, 256),
+])
+@pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 1), (0, 2)])
+def test_primary_hit_ids_match_the_reference(fixture, file, cam, size, traversal, kernel, request):
+    sc = request.getfixturevalue(fixture)
+    g = golden(file)
+    check_scene(sc, g)
+    ids = gpu_primary_ids(sc, cam, size, size, int(g["time"]), traversal, kernel)
+    assert (ids == g["ids"]).all()
+
+
+@pytest.mark.parametrize("fixture,file", [("cornell", "rays_cornell.npz"), ("soup50k", "rays_soup.npz"),
+                                          ("knot_small", "rays_knot.npz")])
+@pytest.mark.parametrize("traversal", [0, 1])
+def test_ray_batches_match_the_reference(fixture, file, traversal, request):
+    sc = request.getfixturevalue(fixture)
+    g = golden(file)
+    check_scene(sc, g)
+    n = g["point_tmax"].shape[0]
+    tb, bb = capi.Buffer(sc.triangles), capi.Buffer(sc.bvh)
+    ro, rd, hb = capi.Buffer(g["point_tmax"]), capi.Buffer(g["dir_flags"]), capi.Buffer(nbytes=16 * n)
+    capi.set_option(capi.OPT_TRAVERSAL, traversal)
+    capi.trace_rays(tb, bb, ro, rd, hb, n)
+    capi.set_option(capi.OPT_TRAVERSAL, 0)
+    got = hb.read(np.uint32).reshape(n, 4)
+    ref = g["hits_bits"]
+    anyhit = (g["dir_flags"][:, 3].view(np.uint32) & 1) == 1
+    assert (got[~anyhit] == ref[~anyhit]).all()  # t, barycentrics, triangle index: bit-exact
+    # any-hit rays stop at the first blocker found: occlusion must agree, the blocker need not
+    assert ((got[anyhit, 3].view(np.int32) >= 0) == (ref[anyhit, 3].view(np.int32) >= 0)).all()
+    assert ((ref[:, 3].view(np.int32) >= 0).mean() > 0.2)
+
+
+def test_cornell_sixteen_samples_against_the_reference(cornell):
+    """The reference's whole per-sample schedule (raytrace, accumulate, copy, post-process) x16."""
+    g = golden("cornell_radiance.npz")
+    check_scene(cornell, g)
+    w = h = 128
+    cam = S.Camera(width=w, height=h, **S.CORNELL_CAMERA)
+    p = S.make_scene_params(cam, path_tracing=True)
+    rt = Raytracer(0, denoise_available=True)
+    rt.set_scene(cornell, p, w, h)
+    rt.start()
+    pixels = None
+    for s in range(16):
+        pixels = rt.raytrace(int(g["time"]) + s)
+        if s == 0:
+            assert rel_rmse(rt.temp_color_img2.read(), g["color_1spp"]) <= RADIANCE_TOL
+            assert rel_rmse(rt.albedo_img2.read(), g["albedo_1spp"]) <= RADIANCE_TOL
+            assert rel_rmse(rt.normal_img2.read(), g["normal_1spp"]) <= RADIANCE_TOL
+    color = rt.temp_color_img2.read()
+    assert rel_rmse(color, g["color_16spp"]) <= RADIANCE_TOL
+    assert rel_rmse(rt.albedo_img2.read(), g["albedo_16spp"]) <= RADIANCE_TOL
+    assert rel_rmse(rt.normal_img2.read(), g["normal_16spp"]) <= RADIANCE_TOL
+    assert (color == g["color_16spp"]).all(-1).mean() > 0.999  # in practice every pixel, bit for bit
+    assert (pixels == g["pixels_16spp"]).all()
+    rt.params = S.make_scene_params(cam, path_tracing=True, anti_aliasing=True)
+    rt.kernel_post_process()
+    assert (rt.color_img.read() == g["pixels_16spp_fxaa"]).all()
+
+
+def test_post_process_on_the_reference_plane():
+    g = golden("fxaa_edge.npz")
+    cam = S.Camera(width=32, height=32, **S.CORNELL_CAMERA)
+    src = capi.Image(32, 32, data=g["image"])
+    dst = capi.Image(32, 32, texel_bytes=4)
+    capi.launch_post_process(S.make_scene_params(cam, anti_aliasing=True, exposure=1.5), src, dst, 32, 32)
+    assert (dst.read() == g["pixels_fxaa"]).all()
+    capi.launch_post_process(S.make_scene_params(cam, anti_aliasing=False, exposure=1.5), src, dst, 32, 32)
+    assert (dst.read() == g["pixels_plain"]).all()
+
+
+@pytest.mark.parametrize("fixture,cam,depth", [("knot_small", S.DRAGON_CAMERA, 5), ("knot_small", S.DRAGON_CAMERA, 0),
+                                               ("soup50k", SOUP_CAMERA, 0), ("cornell", S.CORNELL_CAMERA, 1)])
+def test_path_tracing_against_the_oracle(fixture, cam, depth, request):
+    sc = request.getfixturevalue(fixture)
+    O = oracle()
+    w, h = 320, 200  # not multiples of the 64-pixel tile: ragged tile edges
+    p = S.make_scene_params(S.Camera(width=w, height=h, **cam), shading_metallic=0.4, shading_roughness=0.1)
+    rt = Raytracer(0, denoise_available=True)
+    rt.set_scene(sc, p, w, h)
+    capi.set_option(capi.OPT_MAX_DEPTH, depth)
+    capi.reset_counters()
+    rt.kernel_raytrace(42)
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    k = capi.counters()
+    cnt = np.zeros(8, np.uint64)
+    ref = O.kernel_raytrace(sc, p, 42, w, h, denoise_available=1, max_depth=depth, counters=cnt)
+    for img, r in zip((rt.temp_color_img1, rt.albedo_img1, rt.normal_img1), ref):
+        assert rel_rmse(img.read(), r) <= RADIANCE_TOL
+    # the same paths were followed: identical ray and segment counts
+    assert (k["rays_primary"], k["rays_bounce"], k["rays_shadow"], k["path_segments"]) == tuple(int(x) for x in cnt[:4])
+
+
+def test_textures_sky_and_normal_maps_against_the_oracle(knot_small):
+    """BASELINE config 5's shading path: layered material array (bilinear, REPEAT), normal map TBN,
+    equirect sky — on synthetic textures (the reference's image files need a JPEG decoder)."""
+    O = oracle()
+    sc = knot_small
+    rng = np.random.default_rng(8)
+    mats = rng.uniform(0.05, 1.0, (4, 16, 32, 4)).astype(np.float32)
+    mats[3, ..., :3] = 0.5 + 0.3 * rng.standard_normal((16, 32, 3)).astype(np.float32)  # normal map
+    meta = sc.meta.copy()
+    n = meta.shape[0]
+    uv = rng.uniform(-2, 3, (n, 3, 2)).astype(np.float32)
+    meta["texture_coord1"], meta["texture_coord2"], meta["texture_coord3"] = uv[:, 0], uv[:, 1], uv[:, 2]
+    textured = rng.uniform(size=n) < 0.7
+    meta["diffuse_index"][textured] = 0
+    meta["metallic_index"][textured & (rng.uniform(size=n) < 0.5)] = 1
+    meta["roughness_index"][textured & (rng.uniform(size=n) < 0.5)] = 2
+    nm = textured & (rng.uniform(size=n) < 0.5)
+    meta["normal_index"][nm] = 3
+    t = rng.standard_normal((n, 3)).astype(np.float32)
+    meta["tangent1"] = meta["tangent2"] = meta["tangent3"] = t
+    meta["bitangent1"] = meta["bitangent2"] = meta["bitangent3"] = np.cross(meta["normal1"], t).astype(np.float32)
+    import dataclasses
+    sc2 = dataclasses.replace(sc, meta=meta, materials=mats, sky=S.analytic_sky(64, 32))
+    w, h = 256, 144
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), shading_metallic=0.8, shading_roughness=0.5)
+    rt = Raytracer(0, denoise_available=True)
+    rt.set_scene(sc2, p, w, h)
+    capi.set_option(capi.OPT_MAX_DEPTH, 4)
+    rt.kernel_raytrace(5)
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    ref = O.kernel_raytrace(sc2, p, 5, w, h, denoise_available=1, max_depth=4)
+    for img, r in zip((rt.temp_color_img1, rt.albedo_img1, rt.normal_img1), ref):
+        assert rel_rmse(img.read(), r) <= RADIANCE_TOL
+
+
+def test_full_size_culled_traversal_equals_the_reference_walk():
+    """BASELINE config 2 at full size (871k-triangle stand-in, 1920x1080): a size-independent
+    property instead of the oracle — production traversal == reference-order exhaustive walk, for
+    the primary-hit ids and for the radiance of a 5-segment path (every bounce, shadow and MIS ray)."""
+    sc = S.dragon_standin()
+    w, h = 1920, 1080
+    ids = [gpu_primary_ids(sc, S.DRAGON_CAMERA, w, h, 1, traversal=t) for t in (0, 1)]
+    assert (ids[0] == ids[1]).all()
+    assert (ids[0] >= 0).mean() > 0.5
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), shading_metallic=0.4, shading_roughness=0.1)
+    rt = Raytracer(0)
+    rt.set_scene(sc, p, w, h)
+    capi.set_option(capi.OPT_MAX_DEPTH, 5)
+    out = []
+    for t in (0, 1):
+        capi.set_option(capi.OPT_TRAVERSAL, t)
+        rt.kernel_raytrace(1)
+        out.append(rt.temp_color_img1.read())
+    capi.set_option(capi.OPT_TRAVERSAL, 0)
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    assert (out[0] == out[1]).all()
+    # and a band of rows against the oracle
+    O = oracle()
+    ref = O.kernel_raytrace(sc, p, 1, w, h, max_depth=5, rows=(500, 532))[0]
+    assert rel_rmse(out[0][500:532], ref[500:532]) <= RADIANCE_TOL
+
+
+def test_incoherent_ray_batch_on_a_large_soup():
+    """BASELINE config 4 in miniature (2 M triangles, 4 M rays): culled == exhaustive, bitwise."""
+    sc = S.build_scene(S.soup(2_000_000, seed=4))
+    n = 4_000_000
+    pt, df = random_rays(n, seed=5, lo=-1.0, hi=1.0)
+    tb, bb = capi.Buffer(sc.triangles), capi.Buffer(sc.bvh)
+    ro, rd, hb = capi.Buffer(pt), capi.Buffer(df), capi.Buffer(nbytes=16 * n)
+    res = []
+    for t in (0, 1):
+        capi.set_option(capi.OPT_TRAVERSAL, t)
+        capi.trace_rays(tb, bb, ro, rd, hb, n)
+        res.append(hb.read(np.uint32).reshape(n, 4))
+    capi.set_option(capi.OPT_TRAVERSAL, 0)
+    assert (res[0] == res[1]).all()
+    O = oracle()
+    ref = O.trace_rays(sc, pt[:100000], df[:100000]).view(np.uint32)
+    assert (res[0][:100000] == ref).all()
+
+
+def test_tiles_partition_is_bit_identical_to_one_gpu(knot_small):
+    """Multi-GPU rule on one GPU: render the frame as 3 ranks' tile sets, one after the other, into
+    the same image; the union must equal the single-rank frame bit for bit."""
+    w, h = 300, 200
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA))
+    rt = Raytracer(0)
+    rt.set_scene(knot_small, p, w, h)
+    capi.set_option(capi.OPT_MAX_DEPTH, 3)
+    rt.kernel_raytrace(9)
+    whole = rt.temp_color_img1.read()
+    rt.temp_color_img1.fill([0, 0, 0, 0])
+    capi.set_option(capi.OPT_TILE_RANKS, 3)
+    for r in range(3):
+        capi.set_option(capi.OPT_TILE_RANK, r)
+        rt.kernel_raytrace(9)
+    capi.set_option(capi.OPT_TILE_RANK, 0)
+    capi.set_option(capi.OPT_TILE_RANKS, 1)
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    assert (rt.temp_color_img1.read() == whole).all()
+
+
+def test_scene_edge_cases():
+    O = oracle()
+    # one triangle: the BVH root is a leaf
+    tri = np.float32([[-0.5, -0.5, 0, 0.5, -0.5, 0, 0, 0.6, 0]])
+    sc = S.build_scene(tri)
+    assert sc.bvh.shape[0] == 1
+    cam = dict(position=[0, 0, 2], target=[0, 0, 0], up=[0, 1, 0], fovy=45.0)
+    ids = gpu_primary_ids(sc, cam, 64, 64, 1)
+    meta, sky = id_inputs(sc)
+    p = S.make_scene_params(S.Camera(width=64, height=64, **cam), path_tracing=False)
+    ref = S.decode_ids(O.kernel_raytrace(sc, p, 1, 64, 64, meta=meta, sky=sky)[0]).reshape(64, 64)
+    assert (ids == ref).all() and (ids == 0).any() and (ids == -1).any()
+    # a leaf above the 128-triangle chunk limit (300 coincident-centre triangles: no SAH split pays)
+    rng = np.random.default_rng(0)
+    many = (rng.uniform(-0.3, 0.3, (300, 3, 3)) * [1, 1, 0.001]).reshape(300, 9).astype(np.float32)
+    sc = S.build_scene(many)
+    ids = gpu_primary_ids(sc, cam, 64, 64, 1)
+    meta, sky = id_inputs(sc)
+    ref = S.decode_ids(O.kernel_raytrace(sc, p, 1, 64, 64, meta=meta, sky=sky)[0]).reshape(64, 64)
+    assert (ids == ref).all()
+
+
+def test_error_behaviour():
+    # empty inputs are rejected like Accelerator::create_* do (cuda/accelerator/accelerator.hpp:43-45)
+    with pytest.raises(ValueError):
+        capi.Buffer(np.zeros(0, np.float32))
+    with pytest.raises(ValueError):
+        capi.Image(0, 4)
+    # a foreign device pointer surfaces as an error code, not a fault
+    sc = S.cornell_box()
+    tb, bb = capi.Buffer(sc.triangles), capi.Buffer(sc.bvh)
+    lib = capi.load()
+    rc = lib.nova_hip_trace_rays(tb.ptr, bb.ptr, 0x1000, 0x2000, 0x3000, 16)
+    assert rc == -2 and b"not allocated" in lib.nova_hip_error_string(rc)
+    # a malformed BVH (right child pointing backwards) is refused
+    bad = sc.bvh.copy()
+    bad["bottom_num_right"][0, 3] = 0.0
+    bb2 = capi.Buffer(bad)
+    ro, rd, hb = capi.Buffer(np.zeros((4, 4), np.float32)), capi.Buffer(np.zeros((4, 4), np.float32)), capi.Buffer(nbytes=64)
+    assert lib.nova_hip_trace_rays(tb.ptr, bb2.ptr, ro.ptr, rd.ptr, hb.ptr, 4) == -3
+    # rewriting a buffer invalidates the cached scene: results follow the new contents
+    bb3 = capi.Buffer(sc.bvh)
+    pt, df = random_rays(1000, seed=1)
+    ro, rd, hb = capi.Buffer(pt), capi.Buffer(df), capi.Buffer(nbytes=16000)
+    capi.trace_rays(tb, bb3, ro, rd, hb, 1000)
+    first = hb.read(np.uint32).copy()
+    moved = sc.bvh.copy()
+    moved["top_offset_left"][:, :3] += 100.0
+    moved["bottom_num_right"][:, :3] += 100.0
+    bb3.write(moved)
+    capi.trace_rays(tb, bb3, ro, rd, hb, 1000)
+    assert (hb.read(np.int32).reshape(-1, 4)[:, 3] == -1).all() and (first.view(np.int32).reshape(-1, 4)[:, 3] >= 0).any()
