@@ -1,9 +1,10 @@
-"""Generates the golden vectors under tests/golden/ by RUNNING THE REFERENCE: oracle/_ref is Nova's
-own kernel code (kernels/kernels.cu and every header it includes, unmodified, from /root/reference)
-compiled for the CPU on the device-backend shim in oracle/refshim/.  Build container only
-(`make -C oracle ref` first); the GPU box has no /root/reference, it only reads the .npz files.
+"""Generates the vectors under tests/golden/ from oracle/libnova_oracle.so, the CPU restatement of
+Nova's hot path (oracle/nova_oracle.cpp).  PARITY UNPINNED: the reference's kernels cannot be built or
+run in this image and its own tests hold no vectors for them, so these files are
+regression vectors of the restatement — they freeze its behaviour, so that the oracle, the HIP path
+and later rounds are all held to the same numbers — not outputs of the reference.
 
-The vectors hold inputs and expected outputs only (no reference source text):
+The vectors hold inputs and expected outputs only:
   kat.npz               hash, rand, intersects_aabb, CookTorranceBRDF sample/eval/pdf
   ids_*.npz             primary closest-hit triangle id per pixel (kD-encoding trick, see
                         nova_amd.scene.encode_ids_in_kd) for Cornell box 512^2, a 50k-triangle soup
@@ -25,7 +26,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from nova_amd import scene as S  # noqa: E402
-from oracle import refbind as R  # noqa: E402
+from oracle import bind as R  # noqa: E402
 from tests.conftest import random_rays  # noqa: E402
 
 SEED_TIME = 1
@@ -53,14 +54,13 @@ def primary_ids(sc, camera_kw, w, h, time):
 
 
 def main():
-    assert R.available(), "build oracle/_ref first: make -C oracle ref"
     L = R.lib()
     rng = np.random.default_rng(2026)
 
     # ---- known answers of the small device functions --------------------------------------------
     seeds = rng.integers(0, 2 ** 32, 64, dtype=np.uint64).astype(np.uint32)
     seeds[:4] = [0, 1, 61, 0xFFFFFFFF]
-    hashes = np.array([L.ref_hash(int(s)) for s in seeds], np.uint32)
+    hashes = np.array([L.oracle_hash(int(s)) for s in seeds], np.uint32)
     rand_states = np.array([1, 12345, 0x9E3779B9, 0xFFFFFFFF], np.uint32)
     rand_vals = np.zeros((4, 8), np.float32)
     rand_after = np.zeros((4, 8), np.uint32)
@@ -68,7 +68,7 @@ def main():
     for i, s0 in enumerate(rand_states):
         st = np.array([s0], np.uint32)
         for k in range(8):
-            rand_vals[i, k] = L.ref_rand(ctypes.c_void_p(st.ctypes.data))
+            rand_vals[i, k] = L.oracle_rand(ctypes.c_void_p(st.ctypes.data))
             rand_after[i, k] = st[0]
     n = 1000
     ab_p = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
@@ -77,13 +77,11 @@ def main():
     ab_d[::50, 0] = 0.0  # axis-parallel rays: 1/0 = inf, NaN slab bounds
     c0 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
     c1 = c0 + rng.uniform(0, 1, (n, 3)).astype(np.float32)
-    ab_res = np.array([L.ref_intersects_aabb(*(ctypes.c_void_p(np.ascontiguousarray(a[i]).ctypes.data)
-                                               for a in (ab_p, ab_d, c1, c0))) for i in range(n)], np.int32)
     # keep the arrays alive and contiguous per row
     ab_res = np.zeros(n, np.int32)
     for i in range(n):
         rows = [np.ascontiguousarray(a[i]) for a in (ab_p, ab_d, c1, c0)]
-        ab_res[i] = L.ref_intersects_aabb(*[ctypes.c_void_p(r.ctypes.data) for r in rows])
+        ab_res[i] = L.oracle_intersects_aabb(*[ctypes.c_void_p(r.ctypes.data) for r in rows])
     br_out = rng.standard_normal((n, 3)).astype(np.float32)
     br_out /= np.linalg.norm(br_out, axis=1, keepdims=True).astype(np.float32)
     br_n = br_out + 0.6 * rng.standard_normal((n, 3)).astype(np.float32)
@@ -98,7 +96,7 @@ def main():
         o, nn, dd = (np.ascontiguousarray(a[i]) for a in (br_out, br_n, br_dif))
         st = br_rng_after[i:i + 1]
         out = np.zeros(9, np.float32)
-        L.ref_brdf(ctypes.c_void_p(o.ctypes.data), ctypes.c_void_p(nn.ctypes.data),
+        L.oracle_brdf(ctypes.c_void_p(o.ctypes.data), ctypes.c_void_p(nn.ctypes.data),
                    ctypes.c_void_p(dd.ctypes.data), float(br_met[i]), float(br_rough[i]),
                    ctypes.c_void_p(st.ctypes.data), ctypes.c_void_p(out.ctypes.data))
         br_res[i] = out
@@ -123,11 +121,11 @@ def main():
 
     for name, sc in (("soup", soup), ("knot", knot), ("cornell", cornell)):
         pt, df = random_rays(20000, seed=11, anyhit_every=3, tmax_every=4)
-        hits = R.find_intersection(sc, pt, df)
+        hits = R.trace_rays(sc, pt, df)
         save(f"rays_{name}.npz", point_tmax=pt, dir_flags=df, hits_bits=hits.view(np.uint32),
              scene_sha256=scene_hash(sc))
 
-    # ---- Cornell radiance: the reference's per-sample schedule (src/core/raytracer.cpp:169-262) ----
+    # ---- Cornell radiance: the reference's per-sample schedule, restated (src/core/raytracer.cpp:169-262) ----
     w = h = 128
     cam = S.Camera(width=w, height=h, **S.CORNELL_CAMERA)
     p = S.make_scene_params(cam, path_tracing=True)

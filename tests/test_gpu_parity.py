@@ -1,5 +1,5 @@
 """GPU (-m gpu): the HIP path, called through the C ABI (nova_amd.capi -> libnova_hip.so), against
-  * the golden vectors the reference itself produced (tests/golden/*.npz),
+  * the vectors under tests/golden/*.npz (written by the CPU oracle; parity unpinned),
   * the CPU oracle on seeded inputs,
   * and, at BASELINE.json's full sizes, size-independent properties: the production (ordered,
     culled) traversal must equal the reference walk (fixed order, no culling) ray for ray.
@@ -53,7 +53,7 @@ def gpu_primary_ids(sc, cam_kw, w, h, time, traversal=0, kernel=0):
     ("knot_small", "ids_knot_256.npz", S.DRAGON_CAMERA, 256),
 ])
 @pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 1), (0, 2)])
-def test_primary_hit_ids_match_the_reference(fixture, file, cam, size, traversal, kernel, request):
+def test_primary_hit_ids_match_the_golden_vectors(fixture, file, cam, size, traversal, kernel, request):
     sc = request.getfixturevalue(fixture)
     g = golden(file)
     check_scene(sc, g)
@@ -64,7 +64,7 @@ def test_primary_hit_ids_match_the_reference(fixture, file, cam, size, traversal
 @pytest.mark.parametrize("fixture,file", [("cornell", "rays_cornell.npz"), ("soup50k", "rays_soup.npz"),
                                           ("knot_small", "rays_knot.npz")])
 @pytest.mark.parametrize("traversal", [0, 1])
-def test_ray_batches_match_the_reference(fixture, file, traversal, request):
+def test_ray_batches_match_the_golden_vectors(fixture, file, traversal, request):
     sc = request.getfixturevalue(fixture)
     g = golden(file)
     check_scene(sc, g)
@@ -83,7 +83,7 @@ def test_ray_batches_match_the_reference(fixture, file, traversal, request):
     assert ((ref[:, 3].view(np.int32) >= 0).mean() > 0.2)
 
 
-def test_cornell_sixteen_samples_against_the_reference(cornell):
+def test_cornell_sixteen_samples_against_the_golden_vectors(cornell):
     """The reference's whole per-sample schedule (raytrace, accumulate, copy, post-process) x16."""
     g = golden("cornell_radiance.npz")
     check_scene(cornell, g)
@@ -111,7 +111,7 @@ def test_cornell_sixteen_samples_against_the_reference(cornell):
     assert (rt.color_img.read() == g["pixels_16spp_fxaa"]).all()
 
 
-def test_post_process_on_the_reference_plane():
+def test_post_process_on_the_golden_plane():
     g = golden("fxaa_edge.npz")
     cam = S.Camera(width=32, height=32, **S.CORNELL_CAMERA)
     src = capi.Image(32, 32, data=g["image"])

@@ -72,3 +72,43 @@ def test_hex_serialisation_round_trip(cornell):  # triangle.cpp:23-36, bvh.cpp:2
     assert S.to_hex_words(other) != text  # 1.32 vs 1.321 stay distinct (triangle.cpp:38-55)
     back = S.from_hex_words(S.to_hex_words(cornell.bvh), S.BVH_NODE)
     assert back.tobytes() == cornell.bvh.tobytes()
+
+
+def _ref_aabb_lib():
+    import os
+    path = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libnova_ref_aabb.so")
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
+def test_box_helpers_bit_equal_to_the_reference_aabb():
+    """oracle/_ref/libnova_ref_aabb.so = the reference's header-only nova::AABB on its vendored glm,
+    compiled unmodified (oracle/ref_aabb.cpp); exists only where /root/reference does."""
+    import pytest
+
+    R = _ref_aabb_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is built only where /root/reference exists")
+    rng = np.random.default_rng(7)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    empty = np.zeros(6, np.float32)
+    R.ref_aabb_empty(vp(empty))
+    assert (empty[:3] == -FMAX).all() and (empty[3:] == FMAX).all()
+    for i in range(2000):
+        scale = np.float32(10.0 ** rng.integers(-3, 4))
+        b0 = (rng.uniform(-1, 1, 3) * scale).astype(np.float32)
+        t0 = (b0 + rng.uniform(0, 1, 3) * scale).astype(np.float32)
+        b1 = (rng.uniform(-1, 1, 3) * scale).astype(np.float32)
+        t1 = (b1 + rng.uniform(0, 1, 3) * scale).astype(np.float32)
+        n = int(rng.integers(1, 1 << 20))
+        want = np.zeros(5, np.float32)
+        R.ref_aabb(vp(t0), vp(b0), ctypes.c_uint64(n), vp(want))
+        assert aabb(t0, b0, n).tobytes() == want.tobytes(), i
+        g = np.zeros(6, np.float32)
+        R.ref_aabb_combine(0, vp(t0), vp(b0), vp(t1), vp(b1), vp(g))
+        t, b = grow(t0, b0, t1, b1)
+        assert np.concatenate([t, b]).tobytes() == g.tobytes(), i
+        if i % 10 == 0:  # growing the empty box yields the other box (bvh.cpp builds bounds this way)
+            et, eb = empty[:3].copy(), empty[3:].copy()  # keep alive while the pointers are in use
+            R.ref_aabb_combine(0, vp(et), vp(eb), vp(t1), vp(b1), vp(g))
+            t, b = grow(et, eb, t1, b1)
+            assert np.concatenate([t, b]).tobytes() == g.tobytes()
