@@ -30,11 +30,13 @@ static_assert(sizeof(nova_scene_params) == 104, "SceneParams layout");
 static_assert(offsetof(nova_triangle_meta, texture_coord1) == 112, "TriangleMetaData layout");
 static_assert(offsetof(nova_scene_params, path_tracing) == 84, "SceneParams layout");
 static_assert(sizeof(Node64) == 64, "Node64 layout");
+static_assert(sizeof(Node128) == 128, "Node128 layout");
 
 namespace {
 
 constexpr uint32_t kMaxIterations = 1024; // hard cap on path length in unbounded mode
 constexpr uint32_t kTileSize = 64;
+constexpr size_t kHeadWords = static_cast<size_t>(kSubQueues) * kSubQueueStride; // u32 words of one launch's queue heads
 
 #define HIP_TRY(expr)                        \
   do {                                       \
@@ -52,6 +54,9 @@ struct PackedScene {
   const void* tri_ptr = nullptr;
   uint64_t bvh_version = 0, tri_version = 0;
   Node64* nodes = nullptr;
+  Node128* wide = nullptr; // null when the input boxes are not nested (traverse.hpp)
+  uint32_t n_wide = 0;
+  uint32_t stack_need_wide = 0;
   uint32_t n_packed = 0;
   uint32_t n_tris = 0;
   uint32_t stack_need = 0;
@@ -78,9 +83,12 @@ struct Ctx {
   uint64_t next_version = 1;
   std::vector<PackedScene> scenes;
   FrameBuffers fb;
-  uint32_t* d_queues = nullptr;          // [0..kMaxIterations+1] n_active, then queue heads
+  uint32_t* d_queues = nullptr;          // [0..kMaxIterations+1] n_active per iteration
+  uint32_t* d_heads = nullptr;           // per iteration: kSubQueues queue heads, one per 128-byte line
   unsigned long long* d_counters = nullptr; // 8 x u64
   uint32_t* h_pinned = nullptr;          // readback word
+  uint32_t* d_spill = nullptr;           // traversal stack entries beyond the LDS part
+  size_t spill_words = 0;
   // options
   int64_t opt_max_depth = 0, opt_traversal = 0, opt_count_work = 0, opt_tile_rank = 0,
           opt_tile_ranks = 1, opt_kernel = 0;
@@ -114,6 +122,7 @@ void drop_scenes_using(const void* p) {
   for (size_t i = 0; i < g.scenes.size();) {
     if (g.scenes[i].bvh_ptr == p || g.scenes[i].tri_ptr == p) {
       (void) hipFree(g.scenes[i].nodes);
+      (void) hipFree(g.scenes[i].wide);
       g.scenes.erase(g.scenes.begin() + i);
     } else {
       i++;
@@ -161,6 +170,13 @@ struct Packer {
   std::vector<uint32_t> child_node[2];
   uint32_t max_depth = 0;
   bool bad = false;
+  bool nested = true; // every child box lies inside its parent's box
+
+  static bool inside(const nova_bvh_node& c, const nova_bvh_node& p) {
+    return c.top_offset_left.x <= p.top_offset_left.x && c.top_offset_left.y <= p.top_offset_left.y &&
+           c.top_offset_left.z <= p.top_offset_left.z && c.bottom_num_right.x >= p.bottom_num_right.x &&
+           c.bottom_num_right.y >= p.bottom_num_right.y && c.bottom_num_right.z >= p.bottom_num_right.z;
+  }
 
   static bool is_leaf(const nova_bvh_node& n) { return !(n.bottom_num_right.w >= 0.0f); }
 
@@ -228,6 +244,7 @@ struct Packer {
       bad = true;
       return kLeafBit;
     }
+    if (!inside(in[i + 1], n) || !inside(in[right], n)) nested = false;
     const uint32_t slot = new_node();
     int32_t l0, l1;
     const uint32_t r0 = ref_of(i + 1, depth + 1, &l0);
@@ -253,6 +270,92 @@ struct Packer {
     }
     set_child(slot, 0, leaf.top_offset_left, leaf.bottom_num_right, head, lh);
     set_child(slot, 1, leaf.top_offset_left, leaf.bottom_num_right, r1, l1);
+    return slot;
+  }
+};
+
+// ---- box-pair tree -> four-wide tree (traverse.hpp: Node128).  A node's child list starts as its
+// two children; while it has a free slot, the inner child with the largest surface area is
+// replaced by its own two children.  Wide nodes are numbered in DFS pre-order.
+struct WideBuilder {
+  const Packer& pk;
+  const std::vector<float>& leaf_e;
+  const std::vector<float>& node_e;
+  float e_round;
+  std::vector<Node128> out;
+  uint32_t stack_need = 0;
+
+  struct Item {
+    float top[3], bot[3];
+    uint32_t ref;
+    float e;
+    bool inner;
+  };
+
+  void children_of(uint32_t n, std::vector<Item>& items) const {
+    const Node64& nd = pk.out[n];
+    for (int k = 0; k < 2; k++) {
+      const int32_t l = pk.child_leaf[k][n];
+      if (l == -2) continue; // unused slot of the synthetic single-leaf root
+      Item it;
+      if (k == 0) {
+        it.top[0] = nd.a.x; it.top[1] = nd.a.y; it.top[2] = nd.a.z;
+        it.bot[0] = nd.b.x; it.bot[1] = nd.b.y; it.bot[2] = nd.b.z;
+      } else {
+        it.top[0] = nd.c.x; it.top[1] = nd.c.y; it.top[2] = nd.c.z;
+        it.bot[0] = nd.d.x; it.bot[1] = nd.d.y; it.bot[2] = nd.d.z;
+      }
+      it.ref = pk.child_node[k][n];
+      it.inner = (l == -1);
+      it.e = (it.inner ? node_e[it.ref] : leaf_e[l]) + e_round;
+      items.push_back(it);
+    }
+  }
+  static float area(const Item& it) {
+    const float dx = it.top[0] - it.bot[0], dy = it.top[1] - it.bot[1], dz = it.top[2] - it.bot[2];
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : 0.0f;
+  }
+
+  // returns the wide index; `above` = stack entries already held when this node is entered
+  uint32_t build(uint32_t n, uint32_t above) {
+    std::vector<Item> items;
+    items.reserve(4);
+    children_of(n, items);
+    while (items.size() < 4) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (size_t i = 0; i < items.size(); i++) {
+        if (items[i].inner && area(items[i]) > best_area) { best = static_cast<int>(i); best_area = area(items[i]); }
+      }
+      if (best < 0) break;
+      const uint32_t child = items[best].ref;
+      items.erase(items.begin() + best);
+      children_of(child, items);
+    }
+    const uint32_t slot = static_cast<uint32_t>(out.size());
+    out.emplace_back();
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    float lo[3][4], hi[3][4], e[4];
+    uint32_t ref[4];
+    for (int k = 0; k < 4; k++) {
+      for (int a = 0; a < 3; a++) { lo[a][k] = qnan; hi[a][k] = qnan; }
+      ref[k] = kEmptyRef;
+      e[k] = 0.0f;
+    }
+    const uint32_t held = above + static_cast<uint32_t>(items.size()) - 1u;
+    stack_need = std::max(stack_need, held);
+    for (size_t k = 0; k < items.size(); k++) {
+      for (int a = 0; a < 3; a++) { lo[a][k] = items[k].bot[a]; hi[a][k] = items[k].top[a]; }
+      e[k] = items[k].e;
+      ref[k] = items[k].inner ? build(items[k].ref, held) : items[k].ref;
+    }
+    Node128& nd = out[slot];
+    for (int a = 0; a < 3; a++) {
+      nd.lo[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+      nd.hi[a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    for (int k = 0; k < 4; k++) { nd.ref[k] = ref[k]; nd.e[k] = e[k]; }
     return slot;
   }
 };
@@ -346,8 +449,18 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   s.root_bot[0] = root.bottom_num_right.x; s.root_bot[1] = root.bottom_num_right.y; s.root_bot[2] = root.bottom_num_right.z;
   HIP_TRY(hipMalloc(&s.nodes, pk.out.size() * sizeof(Node64)));
   hipError_t e = hipMemcpy(s.nodes, pk.out.data(), pk.out.size() * sizeof(Node64), hipMemcpyHostToDevice);
+  if (e == hipSuccess && pk.nested) {
+    WideBuilder wb { pk, leaf_e, node_e, e_round };
+    wb.out.reserve(pk.out.size() / 2 + 2);
+    wb.build(0, 0);
+    s.n_wide = static_cast<uint32_t>(wb.out.size());
+    s.stack_need_wide = wb.stack_need;
+    e = hipMalloc(&s.wide, wb.out.size() * sizeof(Node128));
+    if (e == hipSuccess) e = hipMemcpy(s.wide, wb.out.data(), wb.out.size() * sizeof(Node128), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     (void) hipFree(s.nodes);
+    (void) hipFree(s.wide);
     return static_cast<int>(e);
   }
   g.scenes.push_back(s);
@@ -392,8 +505,51 @@ int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
   return static_cast<int>(hipGetLastError());
 }
 
+constexpr int kWideLdsStack = 16;       // LDS stack entries per lane of k_traverse4 (16 KB per block)
+constexpr int kWideBlocksPerCu = 8;
+
+// k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
+int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
+  const uint32_t need = std::max(s.stack_need, s.stack_need_wide);
+  const unsigned blocks = static_cast<unsigned>(g.num_cus * kWideBlocksPerCu);
+  const size_t threads = static_cast<size_t>(blocks) * 256;
+  const size_t words = need > static_cast<uint32_t>(kWideLdsStack) ? (need - kWideLdsStack) * threads : 0;
+  if (words > g.spill_words) {
+    (void) hipStreamSynchronize(g.stream);
+    (void) hipFree(g.d_spill);
+    g.d_spill = nullptr;
+    g.spill_words = 0;
+    HIP_TRY(hipMalloc(&g.d_spill, words * sizeof(uint32_t)));
+    g.spill_words = words;
+  }
+  A.wide = s.wide;
+  A.spill = g.d_spill;
+  const dim3 grid(blocks), block(256);
+  if (s.wide != nullptr && g.opt_kernel >= 7) {
+    // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
+#define NOVA_LAUNCH_P(RMIN)                                                                                   \
+    do {                                                                                                      \
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN>), grid, block, 0, g.stream, A);  \
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN>), grid, block, 0, g.stream, A);       \
+      return static_cast<int>(hipGetLastError());                                                             \
+    } while (0)
+    switch (g.opt_kernel) {
+      case 8: NOVA_LAUNCH_P(8);
+      case 9: NOVA_LAUNCH_P(32);
+      default: NOVA_LAUNCH_P(16);
+    }
+#undef NOVA_LAUNCH_P
+  }
+  if (count) hipLaunchKernelGGL((k_traverse4<kWideLdsStack, true>), grid, block, 0, g.stream, A);
+  else hipLaunchKernelGGL((k_traverse4<kWideLdsStack, false>), grid, block, 0, g.stream, A);
+  return static_cast<int>(hipGetLastError());
+}
+
 int launch_traverse(const PackedScene& s, TraverseArgs A) {
   A.nodes = s.nodes;
+  A.wide = nullptr;
+  A.spill = nullptr;
+  A.n_tris = s.n_tris;
   A.tris = reinterpret_cast<const float4*>(s.tri_ptr);
   std::memcpy(A.root_top, s.root_top, sizeof(A.root_top));
   std::memcpy(A.root_bot, s.root_bot, sizeof(A.root_bot));
@@ -402,7 +558,9 @@ int launch_traverse(const PackedScene& s, TraverseArgs A) {
   const bool cull = g.opt_traversal == 0, count = g.opt_count_work != 0;
   hipEvent_t e0 = next_event(), e1 = next_event();
   if (e0) (void) hipEventRecord(e0, g.stream);
-  int rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
+  int rc;
+  if (cull && g.opt_kernel >= 6) rc = launch_traverse_wide(s, A, count);
+  else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
   if (e1) (void) hipEventRecord(e1, g.stream);
   if (e0 && e1) g.ev_traverse.push_back({ e0, e1 });
   g.traverse_launches++;
@@ -500,7 +658,8 @@ int nova_hip_init(int device_ordinal) {
   HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
   g.num_cus = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc(&g.d_queues, 2 * (kMaxIterations + 2) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&g.d_queues, (kMaxIterations + 2) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&g.d_heads, kHeadWords * (kMaxIterations + 2) * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&g.d_counters, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&g.h_pinned, 64, hipHostMallocDefault));
@@ -532,7 +691,13 @@ int nova_hip_shutdown(void) {
   if (!g.ready) return 0;
   (void) hipStreamSynchronize(g.stream);
   collect_events();
-  for (auto& s : g.scenes) (void) hipFree(s.nodes);
+  for (auto& s : g.scenes) {
+    (void) hipFree(s.nodes);
+    (void) hipFree(s.wide);
+  }
+  (void) hipFree(g.d_spill);
+  g.d_spill = nullptr;
+  g.spill_words = 0;
   g.scenes.clear();
   for (int s = 0; s < 2; s++) {
     for (int k = 0; k < 6; k++) { (void) hipFree(g.fb.planes[s][k]); g.fb.planes[s][k] = nullptr; }
@@ -810,9 +975,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   F.max_depth = static_cast<uint32_t>(g.opt_max_depth);
   F.n_active = g.d_queues;
   F.block_counters = g.fb.block_counters;
-  uint32_t* queue_heads = g.d_queues + (kMaxIterations + 2);
-
-  HIP_TRY(hipMemsetAsync(g.d_queues, 0, 2 * (kMaxIterations + 2) * sizeof(uint32_t), g.stream));
+  HIP_TRY(hipMemsetAsync(g.d_queues, 0, (kMaxIterations + 2) * sizeof(uint32_t), g.stream));
   const unsigned blocks = (P + 255) / 256;
   const unsigned shade_blocks = (P + kShadeBlock - 1) / kShadeBlock;
   // primary rays = valid pixels of this rank's tiles
@@ -836,6 +999,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   if (!path_tracing) last_it = 0;
   else if (F.max_depth != 0) last_it = nee ? F.max_depth : F.max_depth - 1;
   else last_it = kMaxIterations - 1;
+  HIP_TRY(hipMemsetAsync(g.d_heads, 0, kHeadWords * (last_it + 1) * sizeof(uint32_t), g.stream));
 
   for (uint32_t it = 0; it <= last_it; it++) {
     const int in = it & 1, out = in ^ 1;
@@ -847,7 +1011,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     T.n_items_ptr = g.d_queues + it;
     T.kinds = (nee && it > 0) ? 3u : 1u;
     T.stride = P;
-    T.queue_head = queue_heads + it;
+    T.queue_head = g.d_heads + kHeadWords * it;
     rc = launch_traverse(*scene, T);
     if (rc) return rc;
     {
@@ -954,8 +1118,8 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   PackedScene* scene = nullptr;
   rc = get_scene(bvh, triangles, &scene);
   if (rc) return rc;
-  uint32_t* queue_heads = g.d_queues + (kMaxIterations + 2);
-  HIP_TRY(hipMemsetAsync(queue_heads, 0, sizeof(uint32_t), g.stream));
+  uint32_t* queue_heads = g.d_heads;
+  HIP_TRY(hipMemsetAsync(queue_heads, 0, kHeadWords * sizeof(uint32_t), g.stream));
   TraverseArgs T;
   std::memset(&T, 0, sizeof(T));
   T.ray_o = reinterpret_cast<const float4*>(rays_point_tmax);

@@ -43,12 +43,29 @@ struct __attribute__((aligned(64))) Node64 {
   float4 d; // child1 box min.xyz, w = unused
 };
 
+// Four-wide node (built at upload by collapsing the box-pair tree, see WideBuilder in nova_hip.hip):
+// child k's box is component k of lo[axis] / hi[axis].  An unused slot has a NaN box (never hit).
+// Why collapsing is exact: for a ray whose 1/d and -o/d are finite, the slab bounds
+// fma(c, inv, nio) are monotone in the box coordinate c, so a box contained in another has its
+// [tmin, tmax] contained too: "leaf box pierced" implies "every ancestor box pierced", and the set
+// of triangles the reference reaches is exactly the set of leaves whose OWN box the line pierces —
+// whatever hierarchy is put above them.  Rays with a non-finite 1/d or -o/d (a zero direction
+// component) and trees whose boxes are not nested take the box-pair path, which tests every
+// ancestor like the reference.
+struct __attribute__((aligned(128))) Node128 {
+  float4 lo[3];
+  float4 hi[3];
+  uint32_t ref[4]; // child reference as in Node64; kEmptyRef for an unused slot
+  float e[4];      // cull slack of the child's subtree (world units, slab rounding included)
+};
+
 struct LeafRec {
   uint32_t first, count;
   float top[3], bot[3];
 };
 
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLeafTris = 128;
 constexpr float kCullRel = 0x1p-20f;          // relative slack on the current hit distance
 constexpr float kEvalRounding = 0x1p-20f;     // bound on the fma-chain rounding (gamma_4 = 2^-22, x4)
@@ -68,7 +85,10 @@ struct TraverseArgs {
   uint32_t stride;
   uint32_t* queue_head;
   float inv_radius;                  // 1 / largest |coordinate| of the root box
-  unsigned long long* work_counters; // [0] node fetches, [1] triangle tests (COUNT only)
+  unsigned long long* work_counters; // [0] 64-byte node lines fetched, [1] triangle tests (COUNT only)
+  const Node128* wide;               // four-wide tree, or null when the boxes are not nested
+  uint32_t* spill;                   // stack entries beyond the LDS part: [entry][thread of the grid]
+  uint32_t n_tris;
 };
 
 // Per-leaf cull slack (see the header comment).  For a ray with |origin| <= R and a hit inside
@@ -382,6 +402,445 @@ __global__ __launch_bounds__(256) void k_traverse_ww(TraverseArgs A) {
       } else {
         A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
         cur = kDone;
+      }
+    }
+  }
+  if (COUNT) {
+    unsigned long long a = n_nodes, b = n_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.work_counters[0], a);
+      atomicAdd(&A.work_counters[1], b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Four-wide traversal (production).  Stack: SLDS entries per lane in LDS as [entry][lane], the
+// (rare) rest in a global spill array laid out [entry][thread] so that a wave's spill is coalesced.
+// ---------------------------------------------------------------------------------------------
+template <int SLDS>
+struct HybridStack {
+  uint32_t (*lds)[64];
+  uint32_t* spill; // this thread's column
+  uint32_t stride;
+  uint32_t lane;
+  uint32_t sp = 0;
+  NV_DEV void push(uint32_t v) {
+    if (sp < SLDS) lds[sp][lane] = v;
+    else spill[static_cast<size_t>(sp - SLDS) * stride] = v;
+    sp++;
+  }
+  NV_DEV uint32_t pop() {
+    --sp;
+    return sp < SLDS ? lds[sp][lane] : spill[static_cast<size_t>(sp - SLDS) * stride];
+  }
+};
+
+NV_DEV void ray_setup(float4 o4, float4 d4, RayState& r) {
+  r.d = xyz(d4);
+  r.o = fma3(r.d, kRayEpsilon, xyz(o4)); // kernels/types.hpp:16-20
+  r.inv = { 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };
+  r.nio = (-r.o) * r.inv;
+}
+
+NV_DEV void cswap(float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
+  const bool s = kb < ka;
+  const float k0 = s ? kb : ka, k1 = s ? ka : kb;
+  const uint32_t r0 = s ? rb : ra, r1 = s ? ra : rb;
+  ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+NV_DEV void leaf_tests(const TraverseArgs& A, const RayState& r, HitState& h, uint32_t ref, bool anyhit,
+                       float& far_limit, bool& done, uint32_t& n_tris) {
+  const uint32_t first = ref & 0x00FFFFFFu;
+  const uint32_t end = first + ((ref >> 24) & 0x7Fu) + 1u;
+  // two triangles in flight per step (the second index is clamped so that the load stays inside the
+  // array; its test is skipped when it is past the leaf)
+  for (uint32_t i = first; i < end; i += 2) {
+    const uint32_t i1 = min(i + 1u, A.n_tris - 1u);
+    const float4* m = A.tris + 3 * static_cast<size_t>(i);
+    const float4* q = A.tris + 3 * static_cast<size_t>(i1);
+    const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = q[0], q1 = q[1], q2 = q[2];
+    n_tris++;
+    if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
+      if (anyhit) { done = true; return; }
+      far_limit = fma_(h.t, kCullRel, h.t);
+    }
+    if (i + 1u < end) {
+      n_tris++;
+      if (woop(r, h, static_cast<int>(i + 1u), q0, q1, q2)) {
+        if (anyhit) { done = true; return; }
+        far_limit = fma_(h.t, kCullRel, h.t);
+      }
+    }
+  }
+}
+
+template <int SLDS, bool COUNT>
+__device__ __forceinline__ void trace_wide(const TraverseArgs& A, HybridStack<SLDS>& st, const RayState& r,
+                                           bool anyhit, HitState& h, uint32_t& n_nodes, uint32_t& n_tris) {
+  float tmin, tmax;
+  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
+  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
+  if (!slab(r, rt, rb, tmin, tmax)) return;
+  const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
+  const float slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
+                            max_(1.0f, o_inf * A.inv_radius);
+  float far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
+  const float inf = __builtin_huge_valf();
+  st.sp = 0;
+  uint32_t cur = 0;
+  while (true) {
+    if (!(cur & kLeafBit)) {
+      const Node128* nd = A.wide + cur;
+      const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
+      const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];
+      const uint4 rf = *reinterpret_cast<const uint4*>(nd->ref);
+      const float4 es = *reinterpret_cast<const float4*>(nd->e);
+      if (COUNT) n_nodes += 2;
+      float key[4];
+      uint32_t ref[4] = { rf.x, rf.y, rf.z, rf.w };
+      const float lxs[4] = { lx.x, lx.y, lx.z, lx.w }, lys[4] = { ly.x, ly.y, ly.z, ly.w }, lzs[4] = { lz.x, lz.y, lz.z, lz.w };
+      const float hxs[4] = { hx.x, hx.y, hx.z, hx.w }, hys[4] = { hy.x, hy.y, hy.z, hy.w }, hzs[4] = { hz.x, hz.y, hz.z, hz.w };
+      const float ess[4] = { es.x, es.y, es.z, es.w };
+      uint32_t n_hit = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // kernels/intersection.hpp:40-52 on child k's box (t1 from top, t2 from bottom)
+        const float t1x = fma_(hxs[k], r.inv.x, r.nio.x), t1y = fma_(hys[k], r.inv.y, r.nio.y), t1z = fma_(hzs[k], r.inv.z, r.nio.z);
+        const float t2x = fma_(lxs[k], r.inv.x, r.nio.x), t2y = fma_(lys[k], r.inv.y, r.nio.y), t2z = fma_(lzs[k], r.inv.z, r.nio.z);
+        const float tn = max_(min_(t1x, t2x), max_(min_(t1y, t2y), min_(t1z, t2z)));
+        const float tf = min_(max_(t1x, t2x), min_(max_(t1y, t2y), max_(t1z, t2z)));
+        const float e = ess[k] * slack_scale;
+        const bool hit = (tn <= tf) && (tf + e >= 0.0f) && (tn - e <= far_limit);
+        key[k] = hit ? min_(tn, 3.402823466e38f) : inf; // misses sort after every hit
+        n_hit += hit ? 1u : 0u;
+      }
+      if (n_hit == 0) {
+        if (st.sp == 0) return;
+        cur = st.pop();
+        continue;
+      }
+      if (n_hit > 1) {
+        cswap(key[0], ref[0], key[1], ref[1]);
+        cswap(key[2], ref[2], key[3], ref[3]);
+        cswap(key[0], ref[0], key[2], ref[2]);
+        cswap(key[1], ref[1], key[3], ref[3]);
+        cswap(key[1], ref[1], key[2], ref[2]);
+        if (n_hit > 3) st.push(ref[3]);
+        if (n_hit > 2) st.push(ref[2]);
+        st.push(ref[1]);
+        cur = ref[0];
+      } else {
+        cur = key[0] < inf ? ref[0] : key[1] < inf ? ref[1] : key[2] < inf ? ref[2] : ref[3];
+      }
+      continue;
+    }
+    bool done = false;
+    uint32_t nt = 0;
+    leaf_tests(A, r, h, cur, anyhit, far_limit, done, nt);
+    if (COUNT) n_tris += nt;
+    if (done || st.sp == 0) return;
+    cur = st.pop();
+  }
+}
+
+// Box-pair traversal on the hybrid stack: the path of rays with a non-finite 1/d or -o/d and of
+// trees whose boxes are not nested.  Same steps as trace_one<.., CULL = true, ..>.
+template <int SLDS, bool COUNT>
+__device__ __forceinline__ void trace_pair(const TraverseArgs& A, HybridStack<SLDS>& st, const RayState& r,
+                                           bool anyhit, HitState& h, uint32_t& n_nodes, uint32_t& n_tris) {
+  float tmin, tmax;
+  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
+  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
+  if (!slab(r, rt, rb, tmin, tmax)) return;
+  const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
+  const float slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
+                            max_(1.0f, o_inf * A.inv_radius);
+  float far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
+  st.sp = 0;
+  uint32_t cur = 0;
+  while (true) {
+    if (!(cur & kLeafBit)) {
+      const Node64* nd = A.nodes + cur;
+      const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
+      if (COUNT) n_nodes++;
+      float tmin0, tmax0, tmin1, tmax1;
+      bool h0 = slab(r, na, nb, tmin0, tmax0);
+      bool h1 = slab(r, nc, ndd, tmin1, tmax1);
+      const float es = nc.w * slack_scale;
+      h0 = h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
+      h1 = h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
+      const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
+      if (h0 && h1) {
+        const bool swap = tmin1 < tmin0;
+        st.push(swap ? ref0 : ref1);
+        cur = swap ? ref1 : ref0;
+        continue;
+      }
+      if (h0) { cur = ref0; continue; }
+      if (h1) { cur = ref1; continue; }
+    } else {
+      bool done = false;
+      uint32_t nt = 0;
+      leaf_tests(A, r, h, cur, anyhit, far_limit, done, nt);
+      if (COUNT) n_tris += nt;
+      if (done) return;
+    }
+    if (st.sp == 0) return;
+    cur = st.pop();
+  }
+}
+
+template <int SLDS, bool COUNT>
+__global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
+  __shared__ uint32_t lds_stack[4][SLDS][64];
+  const uint32_t lane = threadIdx.x & 63u;
+  HybridStack<SLDS> st;
+  st.lds = lds_stack[threadIdx.x >> 6];
+  st.lane = lane;
+  st.stride = gridDim.x * blockDim.x;
+  st.spill = A.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
+  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  uint32_t n_nodes = 0, n_tris = 0;
+
+  while (true) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(A.queue_head, 64u);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= total) break;
+    const uint32_t w = base + lane;
+    if (w < total) {
+      const uint32_t kind = w / n;
+      const uint32_t j = w - kind * n;
+      const size_t slot = static_cast<size_t>(kind) * A.stride + j;
+      const float4 o4 = A.ray_o[slot];
+      const float4 d4 = A.ray_d[slot];
+      HitState h { o4.w, 0.0f, 0.0f, -1 };
+      if (!(o4.w < 0.0f)) {
+        RayState r;
+        ray_setup(o4, d4, r);
+        const bool anyhit = (__float_as_uint(d4.w) & 1u) != 0;
+        // finite 1/d and -o/d: x * 0 is 0 for finite x, NaN otherwise
+        const float probe = fma_(r.inv.x, 0.0f, fma_(r.inv.y, 0.0f, r.inv.z * 0.0f)) +
+                            fma_(r.nio.x, 0.0f, fma_(r.nio.y, 0.0f, r.nio.z * 0.0f));
+        if (A.wide != nullptr && probe == 0.0f) trace_wide<SLDS, COUNT>(A, st, r, anyhit, h, n_nodes, n_tris);
+        else trace_pair<SLDS, COUNT>(A, st, r, anyhit, h, n_nodes, n_tris);
+      }
+      A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+    }
+  }
+  if (COUNT) {
+    unsigned long long a = n_nodes, b = n_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.work_counters[0], a);
+      atomicAdd(&A.work_counters[1], b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_traverse_p (production): persistent lanes on the four-wide tree.
+//
+// What bounds traversal on MI355X (rocprofv3 counters): every vector-memory
+// wave-instruction occupies the CU's texture-data path for ~16-25 cycles and every VALU
+// wave-instruction its SIMD for ~4, however few lanes are active — and a 64-ray batch that runs
+// until its longest ray ends keeps only ~10 of 64 lanes busy.  So the unit of cost is the
+// wave-instruction and the lever is lanes per instruction:
+//   * a lane whose ray has ended is refilled from the wave's window of the ray queue as soon as
+//     REFILL_MIN lanes are idle (ray set-up costs three divisions for the whole wave);
+//   * each loop iteration executes ONE phase for the whole wave — a four-wide node step or a
+//     two-triangle leaf step — chosen by majority among the lanes, so neither phase runs for a few
+//     stragglers while the rest of the wave waits;
+//   * the ray queue is split into kSubQueues heads (one 128-byte line each) with 64-ray grabs, so
+//     that the queue atomics of 8192 waves do not serialise on one address and the tail stays
+//     balanced (a wave whose sub-queue is empty moves on to the next one).
+// Per-ray arithmetic is the same as in trace_wide; rays with a non-finite 1/d or -o/d are traced at
+// once on the box-pair tree by their lane (rare).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSubQueues = 64;
+constexpr uint32_t kSubQueueStride = 32; // u32 words between heads (128 bytes)
+
+template <int SLDS, bool COUNT, int REFILL_MIN>
+__global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
+  __shared__ uint32_t lds_stack[4][SLDS][64];
+  const uint32_t lane = threadIdx.x & 63u;
+  HybridStack<SLDS> st;
+  st.lds = lds_stack[threadIdx.x >> 6];
+  st.lane = lane;
+  st.stride = gridDim.x * blockDim.x;
+  st.spill = A.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
+  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  uint32_t n_nodes = 0, n_tris = 0;
+  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
+  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
+  const float inf = __builtin_huge_valf();
+
+  // wave-uniform queue state
+  const uint32_t per = (((total + kSubQueues - 1u) / kSubQueues) + 63u) & ~63u;
+  uint32_t q = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kSubQueues;
+  uint32_t q_tried = 0;
+  uint32_t w_next = 0, w_end = 0;
+  bool dry = (total == 0);
+
+  RayState r = {};
+  HitState h = { 0.0f, 0.0f, 0.0f, -1 };
+  float slack_scale = 0.0f, far_limit = 0.0f;
+  bool anyhit = false;
+  uint32_t cur = kDone;
+  size_t slot = 0;
+  st.sp = 0;
+
+  while (true) {
+    const uint64_t idle = __ballot(cur == kDone);
+    if (!dry && __popcll(idle) >= REFILL_MIN) {
+      if (w_next >= w_end) {
+        while (q_tried < kSubQueues) {
+          const uint32_t lo = q * per;
+          if (lo < total) {
+            const uint32_t hi = min(lo + per, total);
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(A.queue_head + q * kSubQueueStride, 64u);
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < hi - lo) {
+              w_next = lo + got;
+              w_end = min(w_next + 64u, hi);
+              break;
+            }
+          }
+          q = (q + 1u) % kSubQueues;
+          q_tried++;
+        }
+        if (w_next >= w_end) dry = true;
+      }
+      if (!dry) {
+        const uint32_t take = min(static_cast<uint32_t>(__popcll(idle)), w_end - w_next);
+        const uint32_t my_rank = rank_in_mask(idle);
+        if (cur == kDone && my_rank < take) {
+          const uint32_t w = w_next + my_rank;
+          const uint32_t kind = w / n;
+          const uint32_t j = w - kind * n;
+          slot = static_cast<size_t>(kind) * A.stride + j;
+          const float4 o4 = A.ray_o[slot];
+          const float4 d4 = A.ray_d[slot];
+          h = { o4.w, 0.0f, 0.0f, -1 };
+          bool live = !(o4.w < 0.0f);
+          if (live) {
+            ray_setup(o4, d4, r);
+            anyhit = (__float_as_uint(d4.w) & 1u) != 0;
+            const float probe = fma_(r.inv.x, 0.0f, fma_(r.inv.y, 0.0f, r.inv.z * 0.0f)) +
+                                fma_(r.nio.x, 0.0f, fma_(r.nio.y, 0.0f, r.nio.z * 0.0f));
+            if (!(probe == 0.0f)) {
+              trace_pair<SLDS, COUNT>(A, st, r, anyhit, h, n_nodes, n_tris);
+              live = false;
+            } else {
+              float tmin, tmax;
+              live = slab(r, rt, rb, tmin, tmax);
+            }
+          }
+          if (live) {
+            const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
+            slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
+                          max_(1.0f, o_inf * A.inv_radius);
+            far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
+            st.sp = 0;
+            cur = 0;
+          } else {
+            A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+          }
+        }
+        w_next += take;
+      }
+      continue;
+    }
+    const uint64_t m_node = __ballot(cur < kDone);
+    const uint64_t m_leaf = __ballot((cur & kLeafBit) != 0);
+    if ((m_node | m_leaf) == 0) {
+      if (dry) break;
+      continue; // cannot happen with REFILL_MIN <= 64; kept as a guard
+    }
+    if (__popcll(m_node) >= __popcll(m_leaf)) {
+      if (cur < kDone) {
+        const Node128* nd = A.wide + cur;
+        const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
+        const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];
+        const uint4 rf = *reinterpret_cast<const uint4*>(nd->ref);
+        const float4 es = *reinterpret_cast<const float4*>(nd->e);
+        if (COUNT) n_nodes += 2;
+        float key[4];
+        uint32_t ref[4] = { rf.x, rf.y, rf.z, rf.w };
+        const float lxs[4] = { lx.x, lx.y, lx.z, lx.w }, lys[4] = { ly.x, ly.y, ly.z, ly.w }, lzs[4] = { lz.x, lz.y, lz.z, lz.w };
+        const float hxs[4] = { hx.x, hx.y, hx.z, hx.w }, hys[4] = { hy.x, hy.y, hy.z, hy.w }, hzs[4] = { hz.x, hz.y, hz.z, hz.w };
+        const float ess[4] = { es.x, es.y, es.z, es.w };
+        uint32_t n_hit = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float t1x = fma_(hxs[k], r.inv.x, r.nio.x), t1y = fma_(hys[k], r.inv.y, r.nio.y), t1z = fma_(hzs[k], r.inv.z, r.nio.z);
+          const float t2x = fma_(lxs[k], r.inv.x, r.nio.x), t2y = fma_(lys[k], r.inv.y, r.nio.y), t2z = fma_(lzs[k], r.inv.z, r.nio.z);
+          const float tn = max_(min_(t1x, t2x), max_(min_(t1y, t2y), min_(t1z, t2z)));
+          const float tf = min_(max_(t1x, t2x), min_(max_(t1y, t2y), max_(t1z, t2z)));
+          const float e = ess[k] * slack_scale;
+          const bool hit = (tn <= tf) && (tf + e >= 0.0f) && (tn - e <= far_limit);
+          key[k] = hit ? min_(tn, 3.402823466e38f) : inf;
+          n_hit += hit ? 1u : 0u;
+        }
+        cswap(key[0], ref[0], key[1], ref[1]);
+        cswap(key[2], ref[2], key[3], ref[3]);
+        cswap(key[0], ref[0], key[2], ref[2]);
+        cswap(key[1], ref[1], key[3], ref[3]);
+        cswap(key[1], ref[1], key[2], ref[2]);
+        if (n_hit > 3) st.push(ref[3]);
+        if (n_hit > 2) st.push(ref[2]);
+        if (n_hit > 1) st.push(ref[1]);
+        if (n_hit > 0) {
+          cur = ref[0];
+        } else if (st.sp != 0) {
+          cur = st.pop();
+        } else {
+          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+          cur = kDone;
+        }
+      }
+    } else {
+      if (cur & kLeafBit) {
+        // two triangles of the leaf per step; the leaf's remaining range is kept in `cur`
+        const uint32_t first = cur & 0x00FFFFFFu;
+        const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
+        const uint32_t i1 = min(first + 1u, A.n_tris - 1u);
+        const float4* m = A.tris + 3 * static_cast<size_t>(first);
+        const float4* qm = A.tris + 3 * static_cast<size_t>(i1);
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = qm[0], q1 = qm[1], q2 = qm[2];
+        bool finished = false;
+        if (COUNT) n_tris++;
+        if (woop(r, h, static_cast<int>(first), m0, m1, m2)) {
+          finished = anyhit;
+          far_limit = fma_(h.t, kCullRel, h.t);
+        }
+        if (!finished && count > 1u) {
+          if (COUNT) n_tris++;
+          if (woop(r, h, static_cast<int>(first + 1u), q0, q1, q2)) {
+            finished = anyhit;
+            far_limit = fma_(h.t, kCullRel, h.t);
+          }
+        }
+        if (!finished && count > 2u) {
+          cur = kLeafBit | ((count - 3u) << 24) | (first + 2u);
+        } else if (!finished && st.sp != 0) {
+          cur = st.pop();
+        } else {
+          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+          cur = kDone;
+        }
       }
     }
   }

@@ -12,6 +12,7 @@ p = S.make_scene_params(cam, shading_metallic=0.4, shading_roughness=0.1)
 rt = Raytracer(0)
 rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
+capi.set_option(capi.OPT_TRAVERSE_KERNEL, int(os.environ.get('NOVA_KERNEL', '0')))
 rt.start()
 for i in range(n):
     rt.raytrace(1 + i, read_back=False)
