@@ -221,7 +221,8 @@ enum {
   NOVA_HIP_OPT_TILE_RANK = 4,   /* image-tile partition for multi-GPU: this process renders the */
   NOVA_HIP_OPT_TILE_RANKS = 5,  /* tiles with (tile_id % ranks) == rank; tiles are 64x64 pixels; */
                                 /* pixels of other tiles are left untouched by kernel_raytrace */
-  NOVA_HIP_OPT_TRAVERSE_KERNEL = 6 /* internal A/B switch between traversal kernel variants */
+  NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* internal A/B switch between traversal kernel variants */
+  NOVA_HIP_OPT_TUNE = 7         /* internal: largest queue grab of a wave, in rays (0 = built-in 64) */
 };
 int nova_hip_set_option(int option, int64_t value);
 int nova_hip_get_option(int option, int64_t* value);

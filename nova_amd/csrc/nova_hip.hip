@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -91,7 +92,7 @@ struct Ctx {
   size_t spill_words = 0;
   // options
   int64_t opt_max_depth = 0, opt_traversal = 0, opt_count_work = 0, opt_tile_rank = 0,
-          opt_tile_ranks = 1, opt_kernel = 0;
+          opt_tile_ranks = 1, opt_kernel = 0, opt_tune = 0;
   // timing
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -524,19 +525,21 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   }
   A.wide = s.wide;
   A.spill = g.d_spill;
+  A.rays_per_wave = g.opt_tune > 0 ? static_cast<uint32_t>(g.opt_tune) : 64u;
   const dim3 grid(blocks), block(256);
-  if (s.wide != nullptr && g.opt_kernel >= 7) {
+  if (s.wide != nullptr && g.opt_kernel != 6) {
     // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
-#define NOVA_LAUNCH_P(RMIN)                                                                                   \
-    do {                                                                                                      \
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN>), grid, block, 0, g.stream, A);  \
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN>), grid, block, 0, g.stream, A);       \
-      return static_cast<int>(hipGetLastError());                                                             \
+#define NOVA_LAUNCH_P(RMIN, MINW)                                                                                   \
+    do {                                                                                                            \
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW>), grid, block, 0, g.stream, A);  \
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW>), grid, block, 0, g.stream, A);       \
+      return static_cast<int>(hipGetLastError());                                                                   \
     } while (0)
     switch (g.opt_kernel) {
-      case 8: NOVA_LAUNCH_P(8);
-      case 9: NOVA_LAUNCH_P(32);
-      default: NOVA_LAUNCH_P(16);
+      case 7: NOVA_LAUNCH_P(16, 6);
+      case 9: NOVA_LAUNCH_P(32, 6);
+      case 10: NOVA_LAUNCH_P(4, 6);
+      default: NOVA_LAUNCH_P(8, 6);
     }
 #undef NOVA_LAUNCH_P
   }
@@ -545,7 +548,7 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   return static_cast<int>(hipGetLastError());
 }
 
-int launch_traverse(const PackedScene& s, TraverseArgs A) {
+int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   A.nodes = s.nodes;
   A.wide = nullptr;
   A.spill = nullptr;
@@ -559,7 +562,11 @@ int launch_traverse(const PackedScene& s, TraverseArgs A) {
   hipEvent_t e0 = next_event(), e1 = next_event();
   if (e0) (void) hipEventRecord(e0, g.stream);
   int rc;
-  if (cull && g.opt_kernel >= 6) rc = launch_traverse_wide(s, A, count);
+  // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays —
+  // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
+  // is the fastest (measured).  11 = that batch kernel for every launch.
+  const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10));
+  if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
   if (e1) (void) hipEventRecord(e1, g.stream);
   if (e0 && e1) g.ev_traverse.push_back({ e0, e1 });
@@ -853,6 +860,7 @@ int nova_hip_set_option(int option, int64_t value) {
       if (value < 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_tile_ranks = value; return 0;
     case NOVA_HIP_OPT_TRAVERSE_KERNEL: g.opt_kernel = value; return 0;
+    case NOVA_HIP_OPT_TUNE: g.opt_tune = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -866,6 +874,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_TILE_RANK: *value = g.opt_tile_rank; return 0;
     case NOVA_HIP_OPT_TILE_RANKS: *value = g.opt_tile_ranks; return 0;
     case NOVA_HIP_OPT_TRAVERSE_KERNEL: *value = g.opt_kernel; return 0;
+    case NOVA_HIP_OPT_TUNE: *value = g.opt_tune; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1012,7 +1021,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     T.kinds = (nee && it > 0) ? 3u : 1u;
     T.stride = P;
     T.queue_head = g.d_heads + kHeadWords * it;
-    rc = launch_traverse(*scene, T);
+    rc = launch_traverse(*scene, T, it == 0);
     if (rc) return rc;
     {
       hipEvent_t e0 = next_event(), e1 = next_event();
@@ -1032,6 +1041,13 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   }
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
+  if (std::getenv("NOVA_HIP_TRACE_QUEUES")) { // diagnostics: paths alive at the start of each iteration
+    std::vector<uint32_t> na(std::min<uint32_t>(last_it + 2, 16));
+    HIP_TRY(hipMemcpy(na.data(), g.d_queues, na.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "nova_hip: paths per iteration:");
+    for (uint32_t v : na) std::fprintf(stderr, " %u", v);
+    std::fprintf(stderr, "\n");
+  }
   return 0;
 }
 
@@ -1130,7 +1146,7 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   T.kinds = 1;
   T.stride = 0;
   T.queue_head = queue_heads;
-  rc = launch_traverse(*scene, T);
+  rc = launch_traverse(*scene, T, false);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();

@@ -89,6 +89,7 @@ struct TraverseArgs {
   const Node128* wide;               // four-wide tree, or null when the boxes are not nested
   uint32_t* spill;                   // stack entries beyond the LDS part: [entry][thread of the grid]
   uint32_t n_tris;
+  uint32_t rays_per_wave;            // k_traverse_p: largest number of rays a wave takes from the queue at a time
 };
 
 // Per-leaf cull slack (see the header comment).  For a ray with |origin| <= R and a hit inside
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
 constexpr uint32_t kSubQueues = 64;
 constexpr uint32_t kSubQueueStride = 32; // u32 words between heads (128 bytes)
 
-template <int SLDS, bool COUNT, int REFILL_MIN>
-__global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
+template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   __shared__ uint32_t lds_stack[4][SLDS][64];
   const uint32_t lane = threadIdx.x & 63u;
   HybridStack<SLDS> st;
@@ -686,9 +687,15 @@ __global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
   const float inf = __builtin_huge_valf();
 
-  // wave-uniform queue state
-  const uint32_t per = (((total + kSubQueues - 1u) / kSubQueues) + 63u) & ~63u;
-  uint32_t q = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kSubQueues;
+  // wave-uniform queue state.  A launch with few rays is latency-bound (the chip is nearly empty
+  // and a wave lasts as long as its longest ray), so rays are dealt thinly: the grab shrinks until
+  // every wave of the grid gets some.  A.rays_per_wave (tuning knob) caps the grab.
+  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * 4u;
+  const uint32_t grab = min(A.rays_per_wave, max(2u, total / n_waves));
+  const uint32_t n_sub = kSubQueues;
+  const uint32_t per = (((total + n_sub - 1u) / n_sub) + 63u) & ~63u;
+  uint32_t q = wave_id % n_sub;
   uint32_t q_tried = 0;
   uint32_t w_next = 0, w_end = 0;
   bool dry = (total == 0);
@@ -697,6 +704,7 @@ __global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
   HitState h = { 0.0f, 0.0f, 0.0f, -1 };
   float slack_scale = 0.0f, far_limit = 0.0f;
   bool anyhit = false;
+  bool pair = false; // this lane's ray walks the box-pair tree (non-finite 1/d or -o/d)
   uint32_t cur = kDone;
   size_t slot = 0;
   st.sp = 0;
@@ -705,20 +713,24 @@ __global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
     const uint64_t idle = __ballot(cur == kDone);
     if (!dry && __popcll(idle) >= REFILL_MIN) {
       if (w_next >= w_end) {
-        while (q_tried < kSubQueues) {
+        while (q_tried < n_sub) {
           const uint32_t lo = q * per;
           if (lo < total) {
             const uint32_t hi = min(lo + per, total);
-            uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(A.queue_head + q * kSubQueueStride, 64u);
+            // a plain (L2) look first: an exhausted sub-queue costs a load, not an atomic
+            uint32_t got = __hip_atomic_load(A.queue_head + q * kSubQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             got = __builtin_amdgcn_readfirstlane(got);
             if (got < hi - lo) {
+              if (lane == 0) got = atomicAdd(A.queue_head + q * kSubQueueStride, grab);
+              got = __builtin_amdgcn_readfirstlane(got);
+            }
+            if (got < hi - lo) {
               w_next = lo + got;
-              w_end = min(w_next + 64u, hi);
+              w_end = min(w_next + grab, hi);
               break;
             }
           }
-          q = (q + 1u) % kSubQueues;
+          q = (q + 1u) % n_sub;
           q_tried++;
         }
         if (w_next >= w_end) dry = true;
@@ -740,13 +752,9 @@ __global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
             anyhit = (__float_as_uint(d4.w) & 1u) != 0;
             const float probe = fma_(r.inv.x, 0.0f, fma_(r.inv.y, 0.0f, r.inv.z * 0.0f)) +
                                 fma_(r.nio.x, 0.0f, fma_(r.nio.y, 0.0f, r.nio.z * 0.0f));
-            if (!(probe == 0.0f)) {
-              trace_pair<SLDS, COUNT>(A, st, r, anyhit, h, n_nodes, n_tris);
-              live = false;
-            } else {
-              float tmin, tmax;
-              live = slab(r, rt, rb, tmin, tmax);
-            }
+            pair = !(probe == 0.0f);
+            float tmin, tmax;
+            live = slab(r, rt, rb, tmin, tmax);
           }
           if (live) {
             const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
@@ -770,7 +778,33 @@ __global__ __launch_bounds__(256) void k_traverse_p(TraverseArgs A) {
       continue; // cannot happen with REFILL_MIN <= 64; kept as a guard
     }
     if (__popcll(m_node) >= __popcll(m_leaf)) {
-      if (cur < kDone) {
+      if (cur < kDone && pair) {
+        // box-pair step (trace_pair's), for the rare rays the four-wide tree is not exact for
+        const Node64* nd = A.nodes + cur;
+        const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
+        if (COUNT) n_nodes++;
+        float tmin0, tmax0, tmin1, tmax1;
+        bool h0 = slab(r, na, nb, tmin0, tmax0);
+        bool h1 = slab(r, nc, ndd, tmin1, tmax1);
+        const float es = nc.w * slack_scale;
+        h0 = h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
+        h1 = h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
+        const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
+        if (h0 && h1) {
+          const bool swap = tmin1 < tmin0;
+          st.push(swap ? ref0 : ref1);
+          cur = swap ? ref1 : ref0;
+        } else if (h0) {
+          cur = ref0;
+        } else if (h1) {
+          cur = ref1;
+        } else if (st.sp != 0) {
+          cur = st.pop();
+        } else {
+          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+          cur = kDone;
+        }
+      } else if (cur < kDone) {
         const Node128* nd = A.wide + cur;
         const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
         const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];

@@ -9,6 +9,7 @@ from tests.conftest import random_rays
 
 kernels = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,6").split(",")]
 capi.init(0)
+capi.set_option(capi.OPT_TUNE, int(os.environ.get('NOVA_TUNE', '0')))
 ok = True
 
 
