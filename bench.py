@@ -58,14 +58,22 @@ def cpu_baseline_and_work(scene_mod, oracle, sc, params, width, height, time_see
     oracle.kernel_raytrace(sc, params, time_seed, width, height, max_depth=MAX_DEPTH,
                            ordered=True, count_work=True, counters=work)
     wr = int(work[0] + work[1] + work[2])
-    n_node = float(work[4]) / wr
-    n_tri = float(work[5]) / wr
+    # the camera rays alone (they run in their own kernel): the same frame without path tracing
+    cam = np.zeros(8, np.uint64)
+    p_cam = np.array(params, copy=True)
+    p_cam["path_tracing"] = 0
+    oracle.kernel_raytrace(sc, p_cam, time_seed, width, height, ordered=True, count_work=True, counters=cam)
+    assert int(cam[0]) == int(work[0]) and int(cam[1] + cam[2]) == 0
+    n_node = float(work[4] - cam[4]) / (wr - int(cam[0]))
+    n_tri = float(work[5] - cam[5]) / (wr - int(cam[0]))
+    n_node_cam = float(cam[4]) / int(cam[0])
+    n_tri_cam = float(cam[5]) / int(cam[0])
     base = {
         "value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"{spp} spp of the whole {width}x{height} frame, max_depth {MAX_DEPTH}: {rays} rays in "
                   f"{dt:.2f} s, reference-order traversal (kernels/raytrace.hpp:38-102), OpenMP",
     }
-    return base, n_node, n_tri
+    return base, n_node, n_tri, n_node_cam, n_tri_cam
 
 
 def main():
@@ -185,27 +193,38 @@ def main():
             "device": capi.device_name(),
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                "traffic": None, "kernel": "k_traverse"}
+                "traffic": None, "kernel": "k_traverse_p"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bind as O  # checker / reported baseline only; never the measured path
-            base, n_node, n_tri = cpu_baseline_and_work(S, O, sc, params, width, height, SEED)
+            base, n_node, n_tri, n_node_cam, n_tri_cam = cpu_baseline_and_work(S, O, sc, params, width, height, SEED)
             out["cpu_baseline"] = base
+            # dominant kernel = k_traverse_p: every traversal launch but the camera-ray one
             bytes_per_ray = 32.0 * n_node + 48.0 * n_tri + 64.0
-            launches = max(1, int(local[3]))
-            avg_launch_s = k["traverse_ms"] / launches / 1e3
-            bytes_per_launch = bytes_per_ray * rays_local / launches
+            launches = max(1, int(local[3]) - int(k["camera_traverse_launches"]))
+            rays_k = rays_local - int(local[0])
+            avg_launch_s = (k["traverse_ms"] - k["camera_traverse_ms"]) / launches / 1e3
+            bytes_per_launch = bytes_per_ray * rays_k / launches
             achieved = bytes_per_launch / avg_launch_s / 1e9
+            cam_bytes = 32.0 * n_node_cam + 48.0 * n_tri_cam + 64.0
+            cam_s = k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])) / 1e3
             roof.update({
                 "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
                 "n_node_per_ray": round(n_node, 2), "n_tri_per_ray": round(n_tri, 2),
+                "rays_per_launch": round(rays_k / launches, 1),
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                 "valu_ops_per_ray": round(17.0 * n_node + 33.0 * n_tri, 1),
+                "camera_ray_kernel": {
+                    "kernel": "k_traverse", "algorithmic_bytes_per_ray": round(cam_bytes, 1),
+                    "avg_launch_ms": round(cam_s * 1e3, 4),
+                    "achieved": round(cam_bytes * int(local[0]) / max(1, int(k["camera_traverse_launches"])) / max(cam_s, 1e-12) / 1e9, 1),
+                },
             })
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
                     roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)"
                 except Exception:
                     pass
         else:

@@ -231,12 +231,14 @@ typedef struct {
   uint64_t rays_primary;      /* find_intersection calls for first path segments */
   uint64_t rays_bounce;       /* closest-hit calls for later segments and MIS rays */
   uint64_t rays_shadow;       /* any-hit calls */
-  uint64_t node_visits;       /* box-pair nodes fetched (NOVA_HIP_OPT_COUNT_WORK) */
+  uint64_t node_visits;       /* 64-byte node lines fetched (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t triangle_tests;    /* intersects_triangle evaluations (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t path_segments;     /* shaded hits */
   double traverse_ms;         /* device time of traversal kernels since the last reset */
   double shade_ms;            /* device time of generate/shade kernels since the last reset */
   uint64_t traverse_launches;
+  double camera_traverse_ms;  /* the part of traverse_ms / traverse_launches spent on camera-ray */
+  uint64_t camera_traverse_launches; /* launches (first path segments), which run their own kernel */
 } nova_hip_counters;
 int nova_hip_get_counters(nova_hip_counters* out);
 int nova_hip_reset_counters(void);

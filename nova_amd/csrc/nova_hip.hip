@@ -96,9 +96,9 @@ struct Ctx {
   // timing
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_traverse, ev_shade;
-  double traverse_ms = 0, shade_ms = 0;
-  uint64_t traverse_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_traverse, ev_camera, ev_shade;
+  double traverse_ms = 0, camera_ms = 0, shade_ms = 0;
+  uint64_t traverse_launches = 0, camera_launches = 0;
   uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
   uint64_t folded[4] = { 0, 0, 0, 0 }; // block counters of released frame buffers
 };
@@ -150,6 +150,14 @@ void collect_events() {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) g.traverse_ms += ms;
   }
+  for (auto& p : g.ev_camera) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      g.traverse_ms += ms;
+      g.camera_ms += ms;
+    }
+  }
+  g.ev_camera.clear();
   for (auto& p : g.ev_shade) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) g.shade_ms += ms;
@@ -558,7 +566,9 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   std::memcpy(A.root_bot, s.root_bot, sizeof(A.root_bot));
   A.inv_radius = 1.0f / s.radius;
   A.work_counters = g.d_counters;
-  const bool cull = g.opt_traversal == 0, count = g.opt_count_work != 0;
+  // The distance cull argues from "hit point inside the leaf box => inside every ancestor's box"
+  // (traverse.hpp); a tree whose boxes are not nested gets the reference's own exhaustive walk.
+  const bool cull = g.opt_traversal == 0 && s.wide != nullptr, count = g.opt_count_work != 0;
   hipEvent_t e0 = next_event(), e1 = next_event();
   if (e0) (void) hipEventRecord(e0, g.stream);
   int rc;
@@ -569,8 +579,9 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
   if (e1) (void) hipEventRecord(e1, g.stream);
-  if (e0 && e1) g.ev_traverse.push_back({ e0, e1 });
+  if (e0 && e1) (coherent ? g.ev_camera : g.ev_traverse).push_back({ e0, e1 });
   g.traverse_launches++;
+  if (coherent) g.camera_launches++;
   return rc;
 }
 
@@ -903,6 +914,8 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   out->traverse_ms = g.traverse_ms;
   out->shade_ms = g.shade_ms;
   out->traverse_launches = g.traverse_launches;
+  out->camera_traverse_ms = g.camera_ms;
+  out->camera_traverse_launches = g.camera_launches;
   return 0;
 }
 
@@ -915,8 +928,8 @@ int nova_hip_reset_counters(void) {
   if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, 4 * static_cast<size_t>(g.fb.n_blocks) * 8));
   for (auto& f : g.folded) f = 0;
   g.host_primary = 0;
-  g.traverse_ms = g.shade_ms = 0;
-  g.traverse_launches = 0;
+  g.traverse_ms = g.camera_ms = g.shade_ms = 0;
+  g.traverse_launches = g.camera_launches = 0;
   return 0;
 }
 

@@ -50,8 +50,8 @@ struct __attribute__((aligned(64))) Node64 {
 // [tmin, tmax] contained too: "leaf box pierced" implies "every ancestor box pierced", and the set
 // of triangles the reference reaches is exactly the set of leaves whose OWN box the line pierces —
 // whatever hierarchy is put above them.  Rays with a non-finite 1/d or -o/d (a zero direction
-// component) and trees whose boxes are not nested take the box-pair path, which tests every
-// ancestor like the reference.
+// component) take the box-pair path, which tests every ancestor like the reference; trees whose
+// boxes are not nested are not collapsed at all and are walked exhaustively (CULL = false).
 struct __attribute__((aligned(128))) Node128 {
   float4 lo[3];
   float4 hi[3];
@@ -419,6 +419,54 @@ __global__ __launch_bounds__(256) void k_traverse_ww(TraverseArgs A) {
   }
 }
 
+// Ray queue of one launch, as seen by one wave (all members wave-uniform).  The queue is split into
+// kSubQueues heads, one per 128-byte line: 8192 waves taking 64 rays at a time from ONE head
+// serialise on that address (~12-25 ns per atomic, measured: the camera-ray launch of a 1080p frame
+// spent ~0.5 ms there).  Sub-queue k owns the contiguous ray range [k * per, (k + 1) * per); a wave
+// starts at sub-queue (wave id mod kSubQueues) and moves on when it is exhausted, so the tail stays
+// balanced and neighbouring rays stay together.
+constexpr uint32_t kSubQueues = 64;
+constexpr uint32_t kSubQueueStride = 32; // u32 words between heads (128 bytes)
+
+struct RayQueue {
+  uint32_t total, grab, per, q, q_tried, w_next, w_end;
+  bool dry;
+  NV_DEV void init(uint32_t total_, uint32_t grab_) {
+    total = total_;
+    grab = grab_;
+    per = (((total + kSubQueues - 1u) / kSubQueues) + 63u) & ~63u;
+    q = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kSubQueues;
+    q_tried = 0;
+    w_next = w_end = 0;
+    dry = (total == 0);
+  }
+  // makes [w_next, w_end) non-empty, or sets `dry`
+  NV_DEV void fill_window(uint32_t* heads, uint32_t lane) {
+    if (dry || w_next < w_end) return;
+    while (q_tried < kSubQueues) {
+      const uint32_t lo = q * per;
+      if (lo < total) {
+        const uint32_t hi = min(lo + per, total);
+        // a plain (L2) look first: an exhausted sub-queue costs a load, not an atomic
+        uint32_t got = __hip_atomic_load(heads + q * kSubQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got < hi - lo) {
+          if (lane == 0) got = atomicAdd(heads + q * kSubQueueStride, grab);
+          got = __builtin_amdgcn_readfirstlane(got);
+        }
+        if (got < hi - lo) {
+          w_next = lo + got;
+          w_end = min(w_next + grab, hi);
+          return;
+        }
+      }
+      q = (q + 1u) % kSubQueues;
+      q_tried++;
+    }
+    dry = true;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Four-wide traversal (production).  Stack: SLDS entries per lane in LDS as [entry][lane], the
 // (rare) rest in a global spill array laid out [entry][thread] so that a wave's spill is coalesced.
@@ -550,8 +598,8 @@ __device__ __forceinline__ void trace_wide(const TraverseArgs& A, HybridStack<SL
   }
 }
 
-// Box-pair traversal on the hybrid stack: the path of rays with a non-finite 1/d or -o/d and of
-// trees whose boxes are not nested.  Same steps as trace_one<.., CULL = true, ..>.
+// Box-pair traversal on the hybrid stack: the path of rays with a non-finite 1/d or -o/d.
+// Same steps as trace_one<.., CULL = true, ..>.
 template <int SLDS, bool COUNT>
 __device__ __forceinline__ void trace_pair(const TraverseArgs& A, HybridStack<SLDS>& st, const RayState& r,
                                            bool anyhit, HitState& h, uint32_t& n_nodes, uint32_t& n_tris) {
@@ -610,13 +658,15 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
   const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
   uint32_t n_nodes = 0, n_tris = 0;
 
+  RayQueue Q;
+  Q.init(total, 64u);
   while (true) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(A.queue_head, 64u);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= total) break;
-    const uint32_t w = base + lane;
-    if (w < total) {
+    Q.fill_window(A.queue_head, lane);
+    if (Q.dry) break;
+    const uint32_t w = Q.w_next + lane;
+    const uint32_t w_end = Q.w_end;
+    Q.w_next = Q.w_end;
+    if (w < w_end) {
       const uint32_t kind = w / n;
       const uint32_t j = w - kind * n;
       const size_t slot = static_cast<size_t>(kind) * A.stride + j;
@@ -668,9 +718,6 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
 // Per-ray arithmetic is the same as in trace_wide; rays with a non-finite 1/d or -o/d are traced at
 // once on the box-pair tree by their lane (rare).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kSubQueues = 64;
-constexpr uint32_t kSubQueueStride = 32; // u32 words between heads (128 bytes)
-
 template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   __shared__ uint32_t lds_stack[4][SLDS][64];
@@ -687,18 +734,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
   const float inf = __builtin_huge_valf();
 
-  // wave-uniform queue state.  A launch with few rays is latency-bound (the chip is nearly empty
-  // and a wave lasts as long as its longest ray), so rays are dealt thinly: the grab shrinks until
-  // every wave of the grid gets some.  A.rays_per_wave (tuning knob) caps the grab.
-  const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const uint32_t n_waves = gridDim.x * 4u;
-  const uint32_t grab = min(A.rays_per_wave, max(2u, total / n_waves));
-  const uint32_t n_sub = kSubQueues;
-  const uint32_t per = (((total + n_sub - 1u) / n_sub) + 63u) & ~63u;
-  uint32_t q = wave_id % n_sub;
-  uint32_t q_tried = 0;
-  uint32_t w_next = 0, w_end = 0;
-  bool dry = (total == 0);
+  // A launch with few rays is latency-bound (the chip is nearly empty and a wave lasts as long as
+  // its longest ray), so the grab shrinks until every wave of the grid gets some rays.
+  RayQueue Q;
+  Q.init(total, min(A.rays_per_wave, max(2u, total / (gridDim.x * 4u))));
 
   RayState r = {};
   HitState h = { 0.0f, 0.0f, 0.0f, -1 };
@@ -711,35 +750,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
 
   while (true) {
     const uint64_t idle = __ballot(cur == kDone);
-    if (!dry && __popcll(idle) >= REFILL_MIN) {
-      if (w_next >= w_end) {
-        while (q_tried < n_sub) {
-          const uint32_t lo = q * per;
-          if (lo < total) {
-            const uint32_t hi = min(lo + per, total);
-            // a plain (L2) look first: an exhausted sub-queue costs a load, not an atomic
-            uint32_t got = __hip_atomic_load(A.queue_head + q * kSubQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (got < hi - lo) {
-              if (lane == 0) got = atomicAdd(A.queue_head + q * kSubQueueStride, grab);
-              got = __builtin_amdgcn_readfirstlane(got);
-            }
-            if (got < hi - lo) {
-              w_next = lo + got;
-              w_end = min(w_next + grab, hi);
-              break;
-            }
-          }
-          q = (q + 1u) % n_sub;
-          q_tried++;
-        }
-        if (w_next >= w_end) dry = true;
-      }
-      if (!dry) {
-        const uint32_t take = min(static_cast<uint32_t>(__popcll(idle)), w_end - w_next);
+    if (!Q.dry && __popcll(idle) >= REFILL_MIN) {
+      Q.fill_window(A.queue_head, lane);
+      if (!Q.dry) {
+        const uint32_t take = min(static_cast<uint32_t>(__popcll(idle)), Q.w_end - Q.w_next);
         const uint32_t my_rank = rank_in_mask(idle);
         if (cur == kDone && my_rank < take) {
-          const uint32_t w = w_next + my_rank;
+          const uint32_t w = Q.w_next + my_rank;
           const uint32_t kind = w / n;
           const uint32_t j = w - kind * n;
           slot = static_cast<size_t>(kind) * A.stride + j;
@@ -767,14 +784,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
             A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
           }
         }
-        w_next += take;
+        Q.w_next += take;
       }
       continue;
     }
     const uint64_t m_node = __ballot(cur < kDone);
     const uint64_t m_leaf = __ballot((cur & kLeafBit) != 0);
     if ((m_node | m_leaf) == 0) {
-      if (dry) break;
+      if (Q.dry) break;
       continue; // cannot happen with REFILL_MIN <= 64; kept as a guard
     }
     if (__popcll(m_node) >= __popcll(m_leaf)) {
@@ -900,13 +917,15 @@ __global__ __launch_bounds__(256) void k_traverse(TraverseArgs A) {
   const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
   uint32_t n_nodes = 0, n_tris = 0;
 
+  RayQueue Q;
+  Q.init(total, 64u);
   while (true) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(A.queue_head, 64u);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= total) break;
-    const uint32_t w = base + lane;
-    if (w < total) {
+    Q.fill_window(A.queue_head, lane);
+    if (Q.dry) break;
+    const uint32_t w = Q.w_next + lane;
+    const uint32_t w_end = Q.w_end;
+    Q.w_next = Q.w_end;
+    if (w < w_end) {
       const uint32_t kind = w / n;
       const uint32_t j = w - kind * n;
       const size_t slot = static_cast<size_t>(kind) * A.stride + j;

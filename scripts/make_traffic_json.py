@@ -1,0 +1,26 @@
+"""profiles/pmc_traffic.json from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_passes.sh
+<dir> fetch write): HBM-side bytes per launch of the dominant kernel.
+Units and corrections per MI355X_MICROARCH.md §HBM: the counters are in KiB; on gfx950 FETCH_SIZE
+reports half the bytes of a wide coalesced 16-B-per-lane stream and is uncalibrated for other shapes
+(this kernel gathers 16-B pieces of 128-byte nodes and 48-byte triangles), so both the raw figure and
+the doubled one (upper bound) are recorded; WRITE_SIZE is exact for 16-B stores."""
+import csv, glob, json, sys, collections
+root, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
+tot = collections.defaultdict(float)
+cnt = collections.defaultdict(int)
+for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if kernel in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            tot[row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[row["Counter_Name"]] += 1
+fetch = tot["FETCH_SIZE"] * 1024 / max(1, cnt["FETCH_SIZE"])
+write = tot["WRITE_SIZE"] * 1024 / max(1, cnt["WRITE_SIZE"])
+json.dump({
+    "kernel": kernel, "dispatches": cnt["FETCH_SIZE"],
+    "fetch_bytes_per_launch_raw": round(fetch), "write_bytes_per_launch": round(write),
+    "hbm_bytes_per_launch": round(2 * fetch + write),
+    "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads; an upper bound "
+            "for this kernel's gathers) + WRITE_SIZE, averaged over the kernel's dispatches of "
+            "scripts/prof_run.py (dragon stand-in 1080p, max_depth 5, 2 frames)",
+}, open(out, "w"), indent=1)
+print(open(out).read())

@@ -225,6 +225,74 @@ def test_incoherent_ray_batch_on_a_large_soup():
     assert (res[0][:100000] == ref).all()
 
 
+def _trace(sc_tris, sc_bvh, pt, df, traversal=0, kernel=0):
+    n = pt.shape[0]
+    tb, bb = capi.Buffer(sc_tris), capi.Buffer(sc_bvh)
+    ro, rd, hb = capi.Buffer(pt), capi.Buffer(df), capi.Buffer(nbytes=16 * n)
+    capi.set_option(capi.OPT_TRAVERSAL, traversal)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, kernel)
+    capi.trace_rays(tb, bb, ro, rd, hb, n)
+    capi.set_option(capi.OPT_TRAVERSAL, 0)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
+    return hb.read(np.uint32).reshape(n, 4)
+
+
+def _irregular_rays(n, seed):
+    """Random rays of which many have exactly-zero direction components (both signs of zero) and
+    origins at 0: their 1/d is infinite and -o/d is NaN, the case the four-wide tree is not exact
+    for (traverse.hpp) and the reference's min/max NaN behaviour decides (kernels/types.hpp:19-20)."""
+    pt, df = random_rays(n, seed=seed, anyhit_every=7, tmax_every=5)
+    d = df[:, :3].copy()
+    d[::11, 0] = 0.0
+    d[::13, 1] = -0.0
+    d[::17, 2] = 0.0
+    d[::11 * 13, :2] = 0.0
+    norm = np.linalg.norm(d, axis=1, keepdims=True)
+    norm[norm == 0] = 1
+    df[:, :3] = d / norm
+    df[::11, 0] = 0.0
+    df[::13, 1] = -0.0
+    pt[::19, :3] = 0.0
+    return pt, df
+
+
+@pytest.mark.parametrize("fixture", ["cornell", "knot_small", "soup50k"])
+@pytest.mark.parametrize("kernel", [0, 6, 11])
+def test_axis_parallel_rays_take_the_exact_path(fixture, kernel, request):
+    sc = request.getfixturevalue(fixture)
+    pt, df = _irregular_rays(100000, seed=31)
+    walk = _trace(sc.triangles, sc.bvh, pt, df, traversal=1)
+    got = _trace(sc.triangles, sc.bvh, pt, df, kernel=kernel)
+    ref = oracle().trace_rays(sc, pt, df).view(np.uint32)
+    anyhit = (df[:, 3].view(np.uint32) & 1) == 1
+    assert (walk[~anyhit] == ref[~anyhit]).all()
+    assert (got[~anyhit] == ref[~anyhit]).all()
+    assert ((got[anyhit, 3].view(np.int32) >= 0) == (ref[anyhit, 3].view(np.int32) >= 0)).all()
+
+
+def test_tree_with_boxes_that_are_not_nested_is_walked_like_the_reference(soup50k):
+    """The four-wide tree is only built when every child box lies inside its parent's.  A tree
+    that violates it (here: some inner boxes shrunk) must still give the reference's answer,
+    which then depends on every ancestor box."""
+    O = oracle()
+    bvh = soup50k.bvh.copy()
+    inner = np.flatnonzero(bvh["bottom_num_right"][:, 3] >= 0)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(inner[1:], 200, replace=False)
+    mid = 0.5 * (bvh["top_offset_left"][pick, :3] + bvh["bottom_num_right"][pick, :3])
+    bvh["top_offset_left"][pick, :3] = mid + 0.25 * (bvh["top_offset_left"][pick, :3] - mid)
+    bvh["bottom_num_right"][pick, :3] = mid + 0.25 * (bvh["bottom_num_right"][pick, :3] - mid)
+    import dataclasses
+    sc = dataclasses.replace(soup50k, bvh=bvh)
+    pt, df = random_rays(200000, seed=8)
+    ref = O.trace_rays(sc, pt, df).view(np.uint32)
+    base = O.trace_rays(soup50k, pt, df).view(np.uint32)
+    assert (ref != base).any()  # the shrunk boxes do hide triangles from the reference walk
+    for kernel in (0, 6):
+        got = _trace(sc.triangles, bvh, pt, df, kernel=kernel)
+        assert (got == ref).all()
+
+
 def test_tiles_partition_is_bit_identical_to_one_gpu(knot_small):
     """Multi-GPU rule on one GPU: render the frame as 3 ranks' tile sets, one after the other, into
     the same image; the union must equal the single-rank frame bit for bit."""
