@@ -537,17 +537,17 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   const dim3 grid(blocks), block(256);
   if (s.wide != nullptr && g.opt_kernel != 6) {
     // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
-#define NOVA_LAUNCH_P(RMIN, MINW)                                                                                   \
-    do {                                                                                                            \
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW>), grid, block, 0, g.stream, A);  \
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW>), grid, block, 0, g.stream, A);       \
-      return static_cast<int>(hipGetLastError());                                                                   \
+#define NOVA_LAUNCH_P(RMIN, MINW, FORK)                                                                                   \
+    do {                                                                                                                  \
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW, FORK>), grid, block, 0, g.stream, A);  \
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW, FORK>), grid, block, 0, g.stream, A);       \
+      return static_cast<int>(hipGetLastError());                                                                         \
     } while (0)
     switch (g.opt_kernel) {
-      case 7: NOVA_LAUNCH_P(16, 6);
-      case 9: NOVA_LAUNCH_P(32, 6);
-      case 10: NOVA_LAUNCH_P(4, 6);
-      default: NOVA_LAUNCH_P(8, 6);
+      case 7: NOVA_LAUNCH_P(16, 6, false);
+      case 9: NOVA_LAUNCH_P(8, 6, false);
+      case 10: NOVA_LAUNCH_P(4, 6, true);
+      default: NOVA_LAUNCH_P(8, 6, true);
     }
 #undef NOVA_LAUNCH_P
   }
@@ -576,7 +576,18 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
   // is the fastest (measured).  11 = that batch kernel for every launch.
   const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10));
-  if (wide) rc = launch_traverse_wide(s, A, count);
+  const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  if (packet) {
+    // production: node and triangles through the scalar cache; 13 = staged through LDS by a
+    // four-lane vector load instead (A/B: 0.79-0.82 ms vs 0.74-0.78 ms on the 1080p camera rays)
+    const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
+    if (g.opt_kernel != 13) {
+      if (count) hipLaunchKernelGGL((k_traverse_packet<true, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+      else hipLaunchKernelGGL((k_traverse_packet<false, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    } else if (count) hipLaunchKernelGGL((k_traverse_packet<true, true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    else hipLaunchKernelGGL((k_traverse_packet<false, true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    rc = static_cast<int>(hipGetLastError());
+  } else if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
   if (e1) (void) hipEventRecord(e1, g.stream);
   if (e0 && e1) (coherent ? g.ev_camera : g.ev_traverse).push_back({ e0, e1 });

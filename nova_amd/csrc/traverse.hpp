@@ -718,9 +718,26 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
 // Per-ray arithmetic is the same as in trace_wide; rays with a non-finite 1/d or -o/d are traced at
 // once on the box-pair tree by their lane (rare).
 // ---------------------------------------------------------------------------------------------
-template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES>
+NV_DEV unsigned long long hit_key(const HitState& h) {
+  // (t, triangle index) ordered like the reference's "closer, ties -> lower index"; t + 0 turns -0 into +0
+  return h.id >= 0 ? (static_cast<unsigned long long>(__float_as_uint(h.t + 0.0f)) << 32) | static_cast<uint32_t>(h.id)
+                   : ~0ull;
+}
+
+template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   __shared__ uint32_t lds_stack[4][SLDS][64];
+  // FORK: records of the rays that were split among several lanes of the wave (index = the lane
+  // that loaded the ray): best (t, index) key, its t bits / u / v, members still running
+  __shared__ unsigned long long rec_key_[4][64];
+  __shared__ float rec_t_[4][64], rec_u_[4][64], rec_v_[4][64];
+  __shared__ uint32_t rec_pending_[4][64], xch_[4][64];
+  unsigned long long* rec_key = rec_key_[threadIdx.x >> 6];
+  float* rec_t = rec_t_[threadIdx.x >> 6];
+  float* rec_u = rec_u_[threadIdx.x >> 6];
+  float* rec_v = rec_v_[threadIdx.x >> 6];
+  uint32_t* rec_pending = rec_pending_[threadIdx.x >> 6];
+  uint32_t* xch = xch_[threadIdx.x >> 6];
   const uint32_t lane = threadIdx.x & 63u;
   HybridStack<SLDS> st;
   st.lds = lds_stack[threadIdx.x >> 6];
@@ -747,6 +764,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   uint32_t cur = kDone;
   size_t slot = 0;
   st.sp = 0;
+  bool fin = false;    // this lane's ray ended in this iteration
+  bool forked = false; // this lane works on a ray shared with other lanes (record rec_*[fam])
+  uint32_t fam = lane;
 
   while (true) {
     const uint64_t idle = __ballot(cur == kDone);
@@ -763,6 +783,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
           const float4 o4 = A.ray_o[slot];
           const float4 d4 = A.ray_d[slot];
           h = { o4.w, 0.0f, 0.0f, -1 };
+          forked = false;
           bool live = !(o4.w < 0.0f);
           if (live) {
             ray_setup(o4, d4, r);
@@ -787,6 +808,54 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         Q.w_next += take;
       }
       continue;
+    }
+    if (FORK && Q.dry && idle != 0) {
+      // Drain: the queue is empty, so an idle lane can only help.  It takes the top stack entry (the
+      // subtree its owner would visit next) of a running lane together with a copy of the ray and
+      // of the best hit so far, and walks it as a ray of its own; the members of such a family
+      // merge their results by (t, index) in the family record, the last one to finish writes the
+      // hit.  The order of visits changes, the set of accepted hits' minimum does not.
+      const bool can_give = cur != kDone && !pair && st.sp >= 1;
+      const uint64_t donors = __ballot(can_give);
+      const uint32_t nf = min(static_cast<uint32_t>(__popcll(idle)), static_cast<uint32_t>(__popcll(donors)));
+      if (nf > 0) {
+        const bool is_donor = can_give && rank_in_mask(donors) < nf;
+        const bool is_helper = cur == kDone && rank_in_mask(idle) < nf;
+        uint32_t give = 0;
+        if (is_donor) {
+          give = st.pop();
+          if (!forked) {
+            fam = lane;
+            rec_key[lane] = hit_key(h);
+            rec_t[lane] = h.t; rec_u[lane] = h.u; rec_v[lane] = h.v;
+            rec_pending[lane] = 1;
+            forked = true;
+          }
+          xch[rank_in_mask(donors)] = lane;
+        }
+        if (is_donor) atomicAdd(&rec_pending[fam], 1u);
+        uint32_t src = lane;
+        if (is_helper) src = xch[rank_in_mask(idle)];
+        give = __shfl(give, src);
+        r.o.x = __shfl(r.o.x, src); r.o.y = __shfl(r.o.y, src); r.o.z = __shfl(r.o.z, src);
+        r.d.x = __shfl(r.d.x, src); r.d.y = __shfl(r.d.y, src); r.d.z = __shfl(r.d.z, src);
+        r.inv.x = __shfl(r.inv.x, src); r.inv.y = __shfl(r.inv.y, src); r.inv.z = __shfl(r.inv.z, src);
+        r.nio.x = __shfl(r.nio.x, src); r.nio.y = __shfl(r.nio.y, src); r.nio.z = __shfl(r.nio.z, src);
+        h.t = __shfl(h.t, src); h.u = __shfl(h.u, src); h.v = __shfl(h.v, src); h.id = __shfl(h.id, src);
+        slack_scale = __shfl(slack_scale, src);
+        far_limit = __shfl(far_limit, src);
+        anyhit = __shfl(anyhit ? 1 : 0, src) != 0;
+        fam = __shfl(fam, src);
+        const uint32_t slot_lo = __shfl(static_cast<uint32_t>(slot), src);
+        const uint32_t slot_hi = __shfl(static_cast<uint32_t>(static_cast<unsigned long long>(slot) >> 32), src);
+        slot = static_cast<size_t>((static_cast<unsigned long long>(slot_hi) << 32) | slot_lo);
+        if (is_helper) {
+          cur = give;
+          st.sp = 0;
+          pair = false;
+          forked = true;
+        }
+      }
     }
     const uint64_t m_node = __ballot(cur < kDone);
     const uint64_t m_leaf = __ballot((cur & kLeafBit) != 0);
@@ -818,11 +887,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         } else if (st.sp != 0) {
           cur = st.pop();
         } else {
-          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-          cur = kDone;
+          fin = true;
         }
       } else if (cur < kDone) {
         const Node128* nd = A.wide + cur;
+        if (FORK && forked) { // another member of the family may have found something closer
+          const float ft = __uint_as_float(static_cast<uint32_t>(rec_key[fam] >> 32));
+          if (ft < h.t) far_limit = min_(far_limit, fma_(ft, kCullRel, ft));
+        }
         const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
         const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];
         const uint4 rf = *reinterpret_cast<const uint4*>(nd->ref);
@@ -858,8 +930,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         } else if (st.sp != 0) {
           cur = st.pop();
         } else {
-          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-          cur = kDone;
+          fin = true;
         }
       }
     } else {
@@ -884,16 +955,194 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
             far_limit = fma_(h.t, kCullRel, h.t);
           }
         }
+        if (FORK && forked && h.id >= 0) atomicMin(&rec_key[fam], hit_key(h));
         if (!finished && count > 2u) {
           cur = kLeafBit | ((count - 3u) << 24) | (first + 2u);
         } else if (!finished && st.sp != 0) {
           cur = st.pop();
         } else {
-          A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-          cur = kDone;
+          fin = true;
         }
       }
     }
+    if (fin) {
+      if (!FORK || !forked) {
+        A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
+      } else {
+        // LDS operations of one wave execute in program order, each for all its lanes: every member
+        // finishing now has merged its key before any of them reads the record back
+        const unsigned long long key = hit_key(h);
+        if (h.id >= 0) atomicMin(&rec_key[fam], key);
+        unsigned long long fk = rec_key[fam];
+        if (h.id >= 0 && fk == key) {
+          rec_t[fam] = h.t; rec_u[fam] = h.u; rec_v[fam] = h.v;
+        }
+        const uint32_t before = atomicSub(&rec_pending[fam], 1u);
+        if (before == 1u) { // last member: the record is final
+          fk = rec_key[fam];
+          if (fk == ~0ull) A.hits[slot] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1));
+          else A.hits[slot] = make_float4(rec_t[fam], rec_u[fam], rec_v[fam], __int_as_float(static_cast<int>(fk & 0xFFFFFFFFull)));
+        }
+        forked = false;
+      }
+      cur = kDone;
+      fin = false;
+    }
+  }
+  if (COUNT) {
+    unsigned long long a = n_nodes, b = n_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&A.work_counters[0], a);
+      atomicAdd(&A.work_counters[1], b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_traverse_packet: camera rays.  A 64-ray batch is one 8x8-pixel block (k_generate), so its rays
+// walk almost the same nodes.  The per-lane kernels then load the same 64 bytes 64 times through the
+// texture path, which is what bounds them (5.1 vector-memory wave-instructions per camera ray,
+// TD busy 67 %).  Here the WAVE walks the box-pair tree once for its 64 rays: the node and the
+// triangles are fetched with wave-uniform addresses (scalar loads through the constant cache: no
+// texture-path traffic at all), every lane tests its own ray against them, and a subtree is entered
+// with the mask of lanes whose own test passed; the stack (one entry per level: reference + lane
+// mask) is wave-uniform in LDS.  Each lane makes exactly the decisions of its own culled traversal
+// (same slab test, same cull test against its own best hit, same triangle test), only the visiting
+// order is the packet's (nearer child by majority), and the result does not depend on the order:
+// min t, ties -> lowest triangle index.  Rays with non-finite 1/d need no special case here: the
+// box-pair tree tests every ancestor like the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPacketStack = 72; // box-pair tree depth <= 64 (checked at upload)
+
+template <bool COUNT, bool STAGED>
+__global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const Node64* __restrict__ nodes,
+                                                         const float4* __restrict__ tris) {
+  __shared__ uint32_t pstack[4][kPacketStack][4];
+  __shared__ float4 pstage[4][64]; // STAGED: a node (4 x 16 B) or up to 21 triangles, loaded once per wave
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t (*stk)[4] = pstack[threadIdx.x >> 6];
+  float4* stage = pstage[threadIdx.x >> 6];
+  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
+  const uint32_t total = n * A.kinds;
+  uint32_t n_nodes = 0, n_tris = 0;
+  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
+  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
+
+  RayQueue Q;
+  Q.init(total, 64u);
+  while (true) {
+    Q.fill_window(A.queue_head, lane);
+    if (Q.dry) break;
+    const uint32_t w = Q.w_next + lane;
+    const bool valid = w < Q.w_end;
+    Q.w_next = Q.w_end;
+    size_t slot = 0;
+    RayState r = {};
+    HitState h = { 0.0f, 0.0f, 0.0f, -1 };
+    bool alive = false, anyhit = false;
+    float slack_scale = 0.0f, far_limit = 0.0f;
+    if (valid) {
+      const uint32_t kind = w / n;
+      const uint32_t j = w - kind * n;
+      slot = static_cast<size_t>(kind) * A.stride + j;
+      const float4 o4 = A.ray_o[slot];
+      const float4 d4 = A.ray_d[slot];
+      h.t = o4.w;
+      if (!(o4.w < 0.0f)) {
+        ray_setup(o4, d4, r);
+        anyhit = (__float_as_uint(d4.w) & 1u) != 0;
+        float tmin, tmax;
+        alive = slab(r, rt, rb, tmin, tmax);
+        const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
+        slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
+                      max_(1.0f, o_inf * A.inv_radius);
+        far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
+      }
+    }
+    uint64_t act = __ballot(alive);
+    uint32_t sp = 0;
+    uint32_t cur = 0;
+    while (act != 0) {
+      const bool in = ((act >> lane) & 1ull) != 0;
+      if (!(cur & kLeafBit)) {
+        float4 na, nb, nc, ndd;
+        if (STAGED) {
+          // four lanes fetch the 64-byte node (one coalesced quad), everyone reads it back from LDS
+          if (lane < 4) stage[lane] = reinterpret_cast<const float4*>(nodes + cur)[lane];
+          na = stage[0]; nb = stage[1]; nc = stage[2]; ndd = stage[3];
+        } else {
+          const Node64* nd = nodes + cur; // wave-uniform address
+          na = nd->a; nb = nd->b; nc = nd->c; ndd = nd->d;
+        }
+        if (COUNT) n_nodes += in ? 1u : 0u;
+        float tmin0, tmax0, tmin1, tmax1;
+        bool h0 = slab(r, na, nb, tmin0, tmax0);
+        bool h1 = slab(r, nc, ndd, tmin1, tmax1);
+        const float es = nc.w * slack_scale;
+        h0 = in && h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
+        h1 = in && h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
+        const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+        const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
+        if (m0 != 0 && m1 != 0) {
+          const uint64_t both = m0 & m1;
+          const uint64_t second_nearer = __ballot(h0 && h1 && tmin1 < tmin0);
+          const bool swap = both != 0 ? (2 * __popcll(second_nearer) > __popcll(both)) : (__popcll(m1) > __popcll(m0));
+          const uint32_t far_ref = swap ? ref0 : ref1;
+          const uint64_t far_mask = swap ? m0 : m1;
+          if (lane == 0) {
+            stk[sp][0] = far_ref;
+            stk[sp][1] = static_cast<uint32_t>(far_mask);
+            stk[sp][2] = static_cast<uint32_t>(far_mask >> 32);
+          }
+          sp++;
+          cur = swap ? ref1 : ref0;
+          act = swap ? m1 : m0;
+          continue;
+        }
+        if (m0 != 0) { cur = ref0; act = m0; continue; }
+        if (m1 != 0) { cur = ref1; act = m1; continue; }
+      } else {
+        const uint32_t first = cur & 0x00FFFFFFu;
+        const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
+        for (uint32_t i = first; i < first + count; i++) {
+          float4 m0, m1, m2;
+          if (STAGED) {
+            // up to 21 triangles (63 x 16 B, contiguous) per vector load
+            const uint32_t k = (i - first) % 21u;
+            if (k == 0) {
+              const uint32_t pieces = 3u * min(21u, first + count - i);
+              if (lane < pieces) stage[lane] = tris[3 * static_cast<size_t>(i) + lane];
+            }
+            m0 = stage[3 * k]; m1 = stage[3 * k + 1]; m2 = stage[3 * k + 2];
+          } else {
+            const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform address
+            m0 = m[0]; m1 = m[1]; m2 = m[2];
+          }
+          if (in && alive) {
+            if (COUNT) n_tris++;
+            if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
+              if (anyhit) alive = false;
+              far_limit = fma_(h.t, kCullRel, h.t);
+            }
+          }
+        }
+      }
+      // pop the next subtree some lane still wants
+      const uint64_t alive_mask = __ballot(alive);
+      act = 0;
+      while (sp != 0 && act == 0) {
+        --sp;
+        cur = __builtin_amdgcn_readfirstlane(stk[sp][0]);
+        const uint64_t mk = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(stk[sp][1])) |
+                            (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(stk[sp][2])) << 32);
+        act = mk & alive_mask;
+      }
+    }
+    if (valid) A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
   }
   if (COUNT) {
     unsigned long long a = n_nodes, b = n_tris;

@@ -93,15 +93,16 @@ def kernel_post_process(params, color2):
     return out
 
 
-def trace_rays(scene, point_tmax, dir_flags, ordered=False, counters=None):
-    """find_intersection on a batch; hits float32[n,4] = (t, u, v, id bits)."""
+def trace_rays(scene, point_tmax, dir_flags, ordered=False, counters=None, per_ray=None):
+    """find_intersection on a batch; hits float32[n,4] = (t, u, v, id bits).  per_ray (optional
+    uint32[n, 2]) receives every ray's box tests and triangle tests."""
     point_tmax = np.ascontiguousarray(point_tmax, np.float32)
     dir_flags = np.ascontiguousarray(dir_flags, np.float32)
     n = point_tmax.shape[0]
     hits = np.zeros((n, 4), np.float32)
-    rc = lib().oracle_trace_rays(_p(scene.triangles), _p(scene.bvh), _p(point_tmax), _p(dir_flags),
-                                 _p(hits), ctypes.c_uint64(n), ctypes.c_int(1 if ordered else 0),
-                                 _p(counters))
+    rc = lib().oracle_trace_rays_work(_p(scene.triangles), _p(scene.bvh), _p(point_tmax), _p(dir_flags),
+                                      _p(hits), ctypes.c_uint64(n), ctypes.c_int(1 if ordered else 0),
+                                      _p(counters), _p(per_ray))
     assert rc == 0
     return hits
 

@@ -893,8 +893,17 @@ int oracle_kernel_post_process(const nova_scene_params* params, const float* col
 
 // find_intersection on a batch; mode 0 = reference walk, 1 = ordered + culled.
 // counters (optional, 2 x uint64): node visits (box tests), triangle tests.
+int oracle_trace_rays_work(const nova_triangle_data* tris, const nova_bvh_node* bvh, const float* point_tmax,
+                           const float* dir_flags, float* hits, uint64_t n_rays, int mode, uint64_t* counters,
+                           uint32_t* per_ray);
 int oracle_trace_rays(const nova_triangle_data* tris, const nova_bvh_node* bvh, const float* point_tmax,
                       const float* dir_flags, float* hits, uint64_t n_rays, int mode, uint64_t* counters) {
+  return oracle_trace_rays_work(tris, bvh, point_tmax, dir_flags, hits, n_rays, mode, counters, nullptr);
+}
+// per_ray (optional, 2 x uint32 per ray): box tests and triangle tests of that ray (work distribution)
+int oracle_trace_rays_work(const nova_triangle_data* tris, const nova_bvh_node* bvh, const float* point_tmax,
+                           const float* dir_flags, float* hits, uint64_t n_rays, int mode, uint64_t* counters,
+                           uint32_t* per_ray) {
   uint64_t cn = 0, ct = 0;
   Slack slack;
   if (mode) slack = compute_slack(tris, bvh);
@@ -907,10 +916,15 @@ int oracle_trace_rays(const nova_triangle_data* tris, const nova_bvh_node* bvh, 
     Hit h;
     h.length = point_tmax[4 * i + 3];
     WorkCount wc;
-    if (mode) find_intersection_ordered(tris, bvh, ray, h, (flags & 1u) != 0, counters ? &wc : nullptr, slack);
-    else find_intersection_reference(tris, bvh, ray, h, (flags & 1u) != 0, counters ? &wc : nullptr);
+    const bool want = counters != nullptr || per_ray != nullptr;
+    if (mode) find_intersection_ordered(tris, bvh, ray, h, (flags & 1u) != 0, want ? &wc : nullptr, slack);
+    else find_intersection_reference(tris, bvh, ray, h, (flags & 1u) != 0, want ? &wc : nullptr);
     cn += wc.nodes;
     ct += wc.tris;
+    if (per_ray) {
+      per_ray[2 * i] = static_cast<uint32_t>(wc.nodes);
+      per_ray[2 * i + 1] = static_cast<uint32_t>(wc.tris);
+    }
     hits[4 * i] = h.length;
     hits[4 * i + 1] = h.bary.y;
     hits[4 * i + 2] = h.bary.z;

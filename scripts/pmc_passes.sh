@@ -3,7 +3,7 @@
 # 4 TCP, 2 TA, 2 TD, 2 GRBM).  usage: pmc_passes.sh <outdir> [pass names...]; NOVA_KERNEL selects the kernel
 set -u
 out=${1:-gpurun_out/pmc}; shift
-want=${*:-tcp1 tcp2 tatd tcc1 sq1 sq2 fetch write grbm}
+want=${*:-tcp1 tcp2 tatd tcc1 sq1 sq2 fetch write grbm sq3 sqc}
 mkdir -p "$out"
 export TMPDIR=/tmp
 pass() {
@@ -22,4 +22,6 @@ pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_
 pass sq2 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_WAVES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM &&
 pass fetch FETCH_SIZE &&
 pass write WRITE_SIZE &&
-pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT &&
+pass sq3 SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY &&
+pass sqc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_BUSY_CYCLES SQC_DCACHE_MISSES_DUPLICATE
