@@ -215,7 +215,7 @@ def main():
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                 "valu_ops_per_ray": round(17.0 * n_node + 33.0 * n_tri, 1),
                 "camera_ray_kernel": {
-                    "kernel": "k_traverse", "algorithmic_bytes_per_ray": round(cam_bytes, 1),
+                    "kernel": "k_traverse_packet", "algorithmic_bytes_per_ray": round(cam_bytes, 1),
                     "avg_launch_ms": round(cam_s * 1e3, 4),
                     "achieved": round(cam_bytes * int(local[0]) / max(1, int(k["camera_traverse_launches"])) / max(cam_s, 1e-12) / 1e9, 1),
                 },

@@ -11,4 +11,4 @@ cat $out/bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err || { echo rocprof failed; tail -5 $out/bench_prof.err; exit 1; }
 bash scripts/pmc_passes.sh $out/pmc fetch write sq1 sq2 tcp1 tatd tcc1 || exit 1
 python3 scripts/pmc_summary.py $out/pmc > $out/pmc_summary.txt
-python3 scripts/make_traffic_json.py $out/pmc k_traverse_p $out/pmc_traffic.json
+python3 scripts/make_traffic_json.py $out/pmc "k_traverse_p<" $out/pmc_traffic.json

@@ -293,6 +293,20 @@ def test_tree_with_boxes_that_are_not_nested_is_walked_like_the_reference(soup50
         assert (got == ref).all()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 5000])
+def test_small_batches_run_in_drain_mode_from_the_start(n, knot_small):
+    """With fewer rays than lanes in the grid the ray queue is empty at once and the persistent
+    kernel splits every running ray among idle lanes (k_traverse_p, FORK): closest hits, bounded rays
+    and any-hit answers must still be the reference's."""
+    sc = knot_small
+    pt, df = random_rays(n, seed=100 + n, anyhit_every=5, tmax_every=3)
+    got = _trace(sc.triangles, sc.bvh, pt, df)
+    ref = oracle().trace_rays(sc, pt, df).view(np.uint32)
+    anyhit = (df[:, 3].view(np.uint32) & 1) == 1
+    assert (got[~anyhit] == ref[~anyhit]).all()
+    assert ((got[anyhit, 3].view(np.int32) >= 0) == (ref[anyhit, 3].view(np.int32) >= 0)).all()
+
+
 def test_tiles_partition_is_bit_identical_to_one_gpu(knot_small):
     """Multi-GPU rule on one GPU: render the frame as 3 ranks' tile sets, one after the other, into
     the same image; the union must equal the single-rank frame bit for bit."""
