@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--grid", type=int, default=660, help="stand-in mesh resolution (2*grid^2 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-frame", action="store_true",
+                    help="N > 1: rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,16 +97,27 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     dist = None
     torch = None
+    # NOVA_BENCH_BACKEND=gloo is the rehearsal mode for boxes with fewer GPUs than ranks: ranks share
+    # devices (local_rank % device_count) and the collectives go through host memory.  The driver's
+    # runs use the default: one rank per GPU, nccl (= RCCL over xGMI).
+    backend = os.environ.get("NOVA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dev_index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
 
     from nova_amd import capi, scene as S, tiles
     from nova_amd.raytracer import Raytracer
 
-    capi.init(local_rank)  # fails loudly without the HIP library / a device
+    capi.init(dev_index)  # fails loudly without the HIP library / a device
     width, height = tiles.weak_scaling_dims(world)
     if args.width and args.height:
         width, height = args.width, args.height
@@ -113,7 +126,7 @@ def main():
     cam = S.Camera(width=width, height=height, **S.DRAGON_CAMERA)
     params = S.make_scene_params(cam, shading_diffuse=(1.0, 1.0, 1.0), shading_metallic=0.4,
                                  shading_roughness=0.1, path_tracing=True, num_samples=args.steps)
-    rt = Raytracer(local_rank)
+    rt = Raytracer(dev_index)
     rt.set_scene(sc, params, width, height)
     capi.set_option(capi.OPT_MAX_DEPTH, MAX_DEPTH)
     capi.set_option(capi.OPT_TILE_RANK, rank)
@@ -128,9 +141,12 @@ def main():
 
     for _ in range(args.warmup):
         rt.raytrace(rt.step_time(SEED), read_back=False)
+    def local_frame():
+        t = tiles.image_as_tensor(rt.color_img, torch.device("cuda", dev_index))
+        return t if coll_device == "cuda" else t.cpu()
+
     if dist is not None:  # warm the collective too
-        tiles.gather_frame(tiles.image_as_tensor(rt.color_img, torch.device("cuda", local_rank)),
-                           width, height, rank, world)
+        tiles.gather_frame(local_frame(), width, height, rank, world)
     rt.start()
     capi.reset_counters()
     barrier()
@@ -139,8 +155,7 @@ def main():
         rt.raytrace(rt.step_time(SEED), read_back=False)
     frame = None
     if dist is not None:
-        frame = tiles.gather_frame(tiles.image_as_tensor(rt.color_img, torch.device("cuda", local_rank)),
-                                   width, height, rank, world)
+        frame = tiles.gather_frame(local_frame(), width, height, rank, world)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -149,10 +164,10 @@ def main():
     trav_ms = k["traverse_ms"]
     shade_ms = k["shade_ms"]
     if dist is not None:
-        tt = torch.tensor([dt, trav_ms, shade_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, trav_ms, shade_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, trav_ms, shade_ms = (float(x) for x in tt.cpu())
-        cc = torch.tensor(local, dtype=torch.float64, device="cuda")
+        cc = torch.tensor(local, dtype=torch.float64, device=coll_device)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         total = cc.cpu().numpy()
     else:
@@ -230,6 +245,16 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["roofline"] = roof
+        if args.check_frame and frame is not None:
+            # the gathered frame against this rank rendering every tile itself, same seeds
+            capi.set_option(capi.OPT_TILE_RANK, 0)
+            capi.set_option(capi.OPT_TILE_RANKS, 1)
+            rt.start()
+            for _ in range(args.steps):
+                rt.raytrace(rt.step_time(SEED), read_back=False)
+            capi.synchronize()
+            alone = tiles.image_as_tensor(rt.color_img, torch.device("cuda", dev_index)).cpu()
+            out["frame_check"] = bool((alone == frame.cpu()).all())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
