@@ -547,7 +547,8 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       case 7: NOVA_LAUNCH_P(16, 6, false);
       case 9: NOVA_LAUNCH_P(8, 6, false);
       case 10: NOVA_LAUNCH_P(4, 6, true);
-      default: NOVA_LAUNCH_P(8, 6, true);
+      case 14: NOVA_LAUNCH_P(8, 6, true);
+      default: NOVA_LAUNCH_P(8, 5, true); // 88-94 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9
     }
 #undef NOVA_LAUNCH_P
   }
@@ -575,7 +576,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays —
   // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
   // is the fastest (measured).  11 = that batch kernel for every launch.
-  const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10));
+  const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10) || g.opt_kernel == 14);
   const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
   if (packet) {
     // production: node and triangles through the scalar cache; 13 = staged through LDS by a

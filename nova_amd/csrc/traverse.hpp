@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
 //   * a lane whose ray has ended is refilled from the wave's window of the ray queue as soon as
 //     REFILL_MIN lanes are idle (ray set-up costs three divisions for the whole wave);
 //   * each loop iteration executes ONE phase for the whole wave — a four-wide node step or a
-//     two-triangle leaf step — chosen by majority among the lanes, so neither phase runs for a few
+//     three-triangle leaf step — chosen by majority among the lanes, so neither phase runs for a few
 //     stragglers while the rest of the wave waits;
 //   * the ray queue is split into kSubQueues heads (one 128-byte line each) with 64-ray grabs, so
 //     that the queue atomics of 8192 waves do not serialise on one address and the tail stays
@@ -718,6 +718,11 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
 // Per-ray arithmetic is the same as in trace_wide; rays with a non-finite 1/d or -o/d are traced at
 // once on the box-pair tree by their lane (rare).
 // ---------------------------------------------------------------------------------------------
+#ifndef NOVA_TRIS_PER_STEP
+#define NOVA_TRIS_PER_STEP 3 // measured on MI355X: 2 -> 3 is 3-9 % faster, 4 needs > 96 VGPRs at 5 waves/SIMD
+#endif
+constexpr int kTrisPerStep = NOVA_TRIS_PER_STEP;
+
 NV_DEV unsigned long long hit_key(const HitState& h) {
   // (t, triangle index) ordered like the reference's "closer, ties -> lower index"; t + 0 turns -0 into +0
   return h.id >= 0 ? (static_cast<unsigned long long>(__float_as_uint(h.t + 0.0f)) << 32) | static_cast<uint32_t>(h.id)
@@ -935,29 +940,31 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
       }
     } else {
       if (cur & kLeafBit) {
-        // two triangles of the leaf per step; the leaf's remaining range is kept in `cur`
+        // kTrisPerStep triangles of the leaf per step (all loads in flight together; indices past
+        // the leaf are clamped into the array and their tests skipped); the leaf's remaining range
+        // is kept in `cur`
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
-        const uint32_t i1 = min(first + 1u, A.n_tris - 1u);
-        const float4* m = A.tris + 3 * static_cast<size_t>(first);
-        const float4* qm = A.tris + 3 * static_cast<size_t>(i1);
-        const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = qm[0], q1 = qm[1], q2 = qm[2];
-        bool finished = false;
-        if (COUNT) n_tris++;
-        if (woop(r, h, static_cast<int>(first), m0, m1, m2)) {
-          finished = anyhit;
-          far_limit = fma_(h.t, kCullRel, h.t);
+        float4 tm[kTrisPerStep][3];
+#pragma unroll
+        for (int k = 0; k < kTrisPerStep; k++) {
+          const float4* m = A.tris + 3 * static_cast<size_t>(min(first + k, A.n_tris - 1u));
+          tm[k][0] = m[0]; tm[k][1] = m[1]; tm[k][2] = m[2];
         }
-        if (!finished && count > 1u) {
-          if (COUNT) n_tris++;
-          if (woop(r, h, static_cast<int>(first + 1u), q0, q1, q2)) {
-            finished = anyhit;
-            far_limit = fma_(h.t, kCullRel, h.t);
+        bool finished = false;
+#pragma unroll
+        for (int k = 0; k < kTrisPerStep; k++) {
+          if (!finished && count > static_cast<uint32_t>(k)) {
+            if (COUNT) n_tris++;
+            if (woop(r, h, static_cast<int>(first + k), tm[k][0], tm[k][1], tm[k][2])) {
+              finished = anyhit;
+              far_limit = fma_(h.t, kCullRel, h.t);
+            }
           }
         }
         if (FORK && forked && h.id >= 0) atomicMin(&rec_key[fam], hit_key(h));
-        if (!finished && count > 2u) {
-          cur = kLeafBit | ((count - 3u) << 24) | (first + 2u);
+        if (!finished && count > static_cast<uint32_t>(kTrisPerStep)) {
+          cur = kLeafBit | ((count - kTrisPerStep - 1u) << 24) | (first + kTrisPerStep);
         } else if (!finished && st.sp != 0) {
           cur = st.pop();
         } else {
