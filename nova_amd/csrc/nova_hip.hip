@@ -19,6 +19,7 @@
 #include "nova_hip.h"
 #include "shade.hpp"
 #include "traverse.hpp"
+#include "traverse_quad.hpp"
 
 using namespace nova_hip;
 
@@ -57,6 +58,13 @@ struct PackedScene {
   Node64* nodes = nullptr;
   Node128* wide = nullptr; // null when the input boxes are not nested (traverse.hpp)
   uint32_t n_wide = 0;
+  // quad-per-ray layout (traverse_quad.hpp); q_wide is null when it could not be built
+  NodeQ* q_wide = nullptr;
+  NodeQ* q_pair = nullptr;
+  TriQuad* q_tris = nullptr;
+  uint32_t* q_slot_tri = nullptr;
+  uint32_t n_tri_quads = 0;
+  bool quad_tried = false;
   uint32_t stack_need_wide = 0;
   uint32_t n_packed = 0;
   uint32_t n_tris = 0;
@@ -119,11 +127,24 @@ const Alloc* find_alloc(const void* p) {
   return it == g.allocs.end() ? nullptr : &it->second;
 }
 
+void free_scene(PackedScene& s) {
+  (void) hipFree(s.nodes);
+  (void) hipFree(s.wide);
+  (void) hipFree(s.q_wide);
+  (void) hipFree(s.q_pair);
+  (void) hipFree(s.q_tris);
+  (void) hipFree(s.q_slot_tri);
+  s.nodes = nullptr;
+  s.wide = nullptr;
+  s.q_wide = s.q_pair = nullptr;
+  s.q_tris = nullptr;
+  s.q_slot_tri = nullptr;
+}
+
 void drop_scenes_using(const void* p) {
   for (size_t i = 0; i < g.scenes.size();) {
     if (g.scenes[i].bvh_ptr == p || g.scenes[i].tri_ptr == p) {
-      (void) hipFree(g.scenes[i].nodes);
-      (void) hipFree(g.scenes[i].wide);
+      free_scene(g.scenes[i]);
       g.scenes.erase(g.scenes.begin() + i);
     } else {
       i++;
@@ -369,12 +390,101 @@ struct WideBuilder {
   }
 };
 
+// ---- quad-per-ray layout (traverse_quad.hpp): both trees as child-major NodeQ arrays whose leaf
+// references count TriQuads, the triangles regrouped so that every leaf starts on a TriQuad, and
+// the slot -> original index table.  Slots follow the order of the original indices (leaves sorted
+// by their first triangle), which is what makes "lowest slot" the reference's tie-break; leaves
+// that overlap would break that, so such a scene keeps the one-ray-per-lane kernel (returns 0 with
+// s.q_wide left null).
+int build_quad_layout(const Packer& pk, const std::vector<Node128>& wide, PackedScene& s, const nova_triangle_data* tris) {
+  const size_t n_leaves = pk.leaves.size();
+  std::vector<uint32_t> order(n_leaves);
+  for (size_t i = 0; i < n_leaves; i++) order[i] = static_cast<uint32_t>(i);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pk.leaves[a].first < pk.leaves[b].first; });
+  std::vector<uint32_t> quad_of_first(s.n_tris, 0xFFFFFFFFu);
+  std::vector<uint32_t> slot_tri;
+  slot_tri.reserve(static_cast<size_t>(s.n_tris) + 3 * n_leaves);
+  uint32_t prev_end = 0;
+  for (uint32_t l : order) {
+    const LeafRec& L = pk.leaves[l];
+    if (L.first < prev_end) return 0; // overlapping leaves
+    prev_end = L.first + L.count;
+    quad_of_first[L.first] = static_cast<uint32_t>(slot_tri.size() / 4);
+    for (uint32_t i = 0; i < L.count; i++) slot_tri.push_back(L.first + i);
+    while (slot_tri.size() % 4 != 0) slot_tri.push_back(0xFFFFFFFFu);
+  }
+  const size_t n_quads = slot_tri.size() / 4;
+  if (n_quads == 0 || n_quads > (1u << 24)) return 0;
+  bool ok = true;
+  auto remap = [&](uint32_t ref) -> uint32_t {
+    if (ref == kEmptyRef || !(ref & kLeafBit)) return ref;
+    const uint32_t q = quad_of_first[ref & 0x00FFFFFFu];
+    if (q == 0xFFFFFFFFu) { ok = false; return kEmptyRef; }
+    return kLeafBit | (ref & 0x7F000000u) | q;
+  };
+  const float qnan = std::numeric_limits<float>::quiet_NaN();
+  std::vector<NodeQ> qw(wide.size());
+  for (size_t i = 0; i < wide.size(); i++) {
+    const Node128& w = wide[i];
+    const float lo[3][4] = { { w.lo[0].x, w.lo[0].y, w.lo[0].z, w.lo[0].w }, { w.lo[1].x, w.lo[1].y, w.lo[1].z, w.lo[1].w },
+                             { w.lo[2].x, w.lo[2].y, w.lo[2].z, w.lo[2].w } };
+    const float hi[3][4] = { { w.hi[0].x, w.hi[0].y, w.hi[0].z, w.hi[0].w }, { w.hi[1].x, w.hi[1].y, w.hi[1].z, w.hi[1].w },
+                             { w.hi[2].x, w.hi[2].y, w.hi[2].z, w.hi[2].w } };
+    for (int k = 0; k < 4; k++) {
+      qw[i].lo_ref[k] = make_float4(lo[0][k], lo[1][k], lo[2][k], __builtin_bit_cast(float, remap(w.ref[k])));
+      qw[i].hi_e[k] = make_float4(hi[0][k], hi[1][k], hi[2][k], w.e[k]);
+    }
+  }
+  std::vector<NodeQ> qp(pk.out.size());
+  for (size_t i = 0; i < pk.out.size(); i++) {
+    const Node64& nd = pk.out[i];
+    const bool second = pk.child_leaf[1][i] != -2; // -2: unused slot of the synthetic single-leaf root
+    const uint32_t r0 = remap(__builtin_bit_cast(uint32_t, nd.a.w));
+    const uint32_t r1 = second ? remap(__builtin_bit_cast(uint32_t, nd.b.w)) : kEmptyRef;
+    qp[i].lo_ref[0] = make_float4(nd.b.x, nd.b.y, nd.b.z, __builtin_bit_cast(float, r0));
+    qp[i].hi_e[0] = make_float4(nd.a.x, nd.a.y, nd.a.z, nd.c.w);
+    qp[i].lo_ref[1] = make_float4(nd.d.x, nd.d.y, nd.d.z, __builtin_bit_cast(float, r1));
+    qp[i].hi_e[1] = make_float4(nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+    for (int k = 2; k < 4; k++) {
+      qp[i].lo_ref[k] = make_float4(qnan, qnan, qnan, __builtin_bit_cast(float, kEmptyRef));
+      qp[i].hi_e[k] = make_float4(qnan, qnan, qnan, 0.0f);
+    }
+  }
+  if (!ok) return 0;
+  hipError_t e = hipMalloc(&s.q_wide, qw.size() * sizeof(NodeQ));
+  if (e == hipSuccess) e = hipMalloc(&s.q_pair, qp.size() * sizeof(NodeQ));
+  if (e == hipSuccess) e = hipMalloc(&s.q_tris, n_quads * sizeof(TriQuad));
+  if (e == hipSuccess) e = hipMalloc(&s.q_slot_tri, slot_tri.size() * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemcpy(s.q_wide, qw.data(), qw.size() * sizeof(NodeQ), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s.q_pair, qp.data(), qp.size() * sizeof(NodeQ), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s.q_slot_tri, slot_tri.data(), slot_tri.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const uint32_t n_slots = static_cast<uint32_t>(slot_tri.size());
+    hipLaunchKernelGGL(k_pack_tri_quads, dim3((n_slots + 255) / 256), dim3(256), 0, g.stream,
+                       reinterpret_cast<const float4*>(tris), s.q_slot_tri, n_slots, reinterpret_cast<float4*>(s.q_tris));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+  }
+  if (e != hipSuccess) {
+    (void) hipFree(s.q_wide); (void) hipFree(s.q_pair); (void) hipFree(s.q_tris); (void) hipFree(s.q_slot_tri);
+    s.q_wide = s.q_pair = nullptr;
+    s.q_tris = nullptr;
+    s.q_slot_tri = nullptr;
+    return static_cast<int>(e);
+  }
+  s.n_tri_quads = static_cast<uint32_t>(n_quads);
+  return 0;
+}
+
 int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedScene** out) {
   const Alloc* ab = find_alloc(bvh);
   const Alloc* at = find_alloc(tris);
   if (!ab || !at) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  // the quad-per-ray layout is an experiment (opt_kernel 16-19): built only when asked for
+  const bool want_quad = g.opt_kernel >= 16 && g.opt_kernel <= 19;
   for (auto& s : g.scenes) {
-    if (s.bvh_ptr == bvh && s.tri_ptr == tris && s.bvh_version == ab->version && s.tri_version == at->version) {
+    if (s.bvh_ptr == bvh && s.tri_ptr == tris && s.bvh_version == ab->version && s.tri_version == at->version &&
+        (!want_quad || s.quad_tried)) {
       *out = &s;
       return 0;
     }
@@ -446,6 +556,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   }
 
   PackedScene s;
+  s.quad_tried = want_quad;
   s.bvh_ptr = bvh;
   s.tri_ptr = tris;
   s.bvh_version = ab->version;
@@ -466,10 +577,10 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
     s.stack_need_wide = wb.stack_need;
     e = hipMalloc(&s.wide, wb.out.size() * sizeof(Node128));
     if (e == hipSuccess) e = hipMemcpy(s.wide, wb.out.data(), wb.out.size() * sizeof(Node128), hipMemcpyHostToDevice);
+    if (e == hipSuccess && want_quad) e = static_cast<hipError_t>(build_quad_layout(pk, wb.out, s, tris));
   }
   if (e != hipSuccess) {
-    (void) hipFree(s.nodes);
-    (void) hipFree(s.wide);
+    free_scene(s);
     return static_cast<int>(e);
   }
   g.scenes.push_back(s);
@@ -557,6 +668,41 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   return static_cast<int>(hipGetLastError());
 }
 
+// k_traverse_q: four lanes per ray (traverse_quad.hpp)
+constexpr int kQuadLdsStack = 24; // LDS stack entries per ray (6 KB per block)
+
+int launch_traverse_quad(const PackedScene& s, TraverseArgs A, bool count) {
+  const uint32_t need = std::max(s.stack_need, s.stack_need_wide) + 1u;
+  const unsigned blocks = static_cast<unsigned>(g.num_cus * 8);
+  const size_t quads = static_cast<size_t>(blocks) * 64;
+  const size_t words = need > static_cast<uint32_t>(kQuadLdsStack) ? (need - kQuadLdsStack) * quads : 0;
+  if (words > g.spill_words) {
+    (void) hipStreamSynchronize(g.stream);
+    (void) hipFree(g.d_spill);
+    g.d_spill = nullptr;
+    g.spill_words = 0;
+    HIP_TRY(hipMalloc(&g.d_spill, words * sizeof(uint32_t)));
+    g.spill_words = words;
+  }
+  A.spill = g.d_spill;
+  A.rays_per_wave = g.opt_tune > 0 ? static_cast<uint32_t>(g.opt_tune) : 32u;
+  QuadArgs G { s.q_wide, s.q_pair, s.q_tris, s.q_slot_tri };
+  const dim3 grid(blocks), block(256);
+#define NOVA_LAUNCH_Q(RMIN, MINW)                                                                                  \
+  do {                                                                                                             \
+    if (count) hipLaunchKernelGGL((k_traverse_q<kQuadLdsStack, true, RMIN, MINW>), grid, block, 0, g.stream, A, G); \
+    else hipLaunchKernelGGL((k_traverse_q<kQuadLdsStack, false, RMIN, MINW>), grid, block, 0, g.stream, A, G);      \
+    return static_cast<int>(hipGetLastError());                                                                    \
+  } while (0)
+  switch (g.opt_kernel) {
+    case 17: NOVA_LAUNCH_Q(4, 8);
+    case 18: NOVA_LAUNCH_Q(1, 8);
+    case 19: NOVA_LAUNCH_Q(2, 7);
+    default: NOVA_LAUNCH_Q(2, 8);
+  }
+#undef NOVA_LAUNCH_Q
+}
+
 int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   A.nodes = s.nodes;
   A.wide = nullptr;
@@ -576,9 +722,13 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays —
   // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
   // is the fastest (measured).  11 = that batch kernel for every launch.
-  const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10) || g.opt_kernel == 14);
-  const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
-  if (packet) {
+  // 16-19 = k_traverse_q (four lanes per ray; measured slower) for every launch
+  const bool quad = cull && s.q_wide != nullptr && g.opt_kernel >= 16 && g.opt_kernel <= 19;
+  const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;
+  const bool wide = cull && !quad && ((base && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10) || g.opt_kernel == 14);
+  const bool packet = cull && !quad && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  if (quad) rc = launch_traverse_quad(s, A, count);
+  else if (packet) {
     // production: node and triangles through the scalar cache; 13 = staged through LDS by a
     // four-lane vector load instead (A/B: 0.79-0.82 ms vs 0.74-0.78 ms on the 1080p camera rays)
     const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
@@ -721,10 +871,7 @@ int nova_hip_shutdown(void) {
   if (!g.ready) return 0;
   (void) hipStreamSynchronize(g.stream);
   collect_events();
-  for (auto& s : g.scenes) {
-    (void) hipFree(s.nodes);
-    (void) hipFree(s.wide);
-  }
+  for (auto& s : g.scenes) free_scene(s);
   (void) hipFree(g.d_spill);
   g.d_spill = nullptr;
   g.spill_words = 0;
