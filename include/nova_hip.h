@@ -222,7 +222,8 @@ enum {
   NOVA_HIP_OPT_TILE_RANKS = 5,  /* tiles with (tile_id % ranks) == rank; tiles are 64x64 pixels; */
                                 /* pixels of other tiles are left untouched by kernel_raytrace */
   NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* internal A/B switch between traversal kernel variants */
-  NOVA_HIP_OPT_TUNE = 7         /* internal: largest queue grab of a wave, in rays (0 = built-in 64) */
+  NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
+                                   bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };
 int nova_hip_set_option(int option, int64_t value);
 int nova_hip_get_option(int option, int64_t* value);

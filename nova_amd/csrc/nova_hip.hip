@@ -644,22 +644,23 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   }
   A.wide = s.wide;
   A.spill = g.d_spill;
-  A.rays_per_wave = g.opt_tune > 0 ? static_cast<uint32_t>(g.opt_tune) : 64u;
+  A.rays_per_wave = (g.opt_tune & 0xFFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFFF) : 64u;
   const dim3 grid(blocks), block(256);
   if (s.wide != nullptr && g.opt_kernel != 6) {
     // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
-#define NOVA_LAUNCH_P(RMIN, MINW, FORK)                                                                                   \
-    do {                                                                                                                  \
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW, FORK>), grid, block, 0, g.stream, A);  \
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW, FORK>), grid, block, 0, g.stream, A);       \
-      return static_cast<int>(hipGetLastError());                                                                         \
+#define NOVA_LAUNCH_P(RMIN, MINW, FORK, LAZY, TPS)                                                                                   \
+    do {                                                                                                                        \
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW, FORK, LAZY, TPS>), grid, block, 0, g.stream, A);  \
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW, FORK, LAZY, TPS>), grid, block, 0, g.stream, A);       \
+      return static_cast<int>(hipGetLastError());                                                                               \
     } while (0)
     switch (g.opt_kernel) {
-      case 7: NOVA_LAUNCH_P(16, 6, false);
-      case 9: NOVA_LAUNCH_P(8, 6, false);
-      case 10: NOVA_LAUNCH_P(4, 6, true);
-      case 14: NOVA_LAUNCH_P(8, 6, true);
-      default: NOVA_LAUNCH_P(8, 5, true); // 88-94 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9
+      case 7: NOVA_LAUNCH_P(16, 6, false, false, 3);
+      case 9: NOVA_LAUNCH_P(8, 6, false, false, 3);
+      case 10: NOVA_LAUNCH_P(4, 6, true, false, 3);
+      case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);
+      case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
+      default: NOVA_LAUNCH_P(8, 5, true, false, 3); // 88-94 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9
     }
 #undef NOVA_LAUNCH_P
   }
@@ -685,7 +686,7 @@ int launch_traverse_quad(const PackedScene& s, TraverseArgs A, bool count) {
     g.spill_words = words;
   }
   A.spill = g.d_spill;
-  A.rays_per_wave = g.opt_tune > 0 ? static_cast<uint32_t>(g.opt_tune) : 32u;
+  A.rays_per_wave = (g.opt_tune & 0xFFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFFF) : 32u;
   QuadArgs G { s.q_wide, s.q_pair, s.q_tris, s.q_slot_tri };
   const dim3 grid(blocks), block(256);
 #define NOVA_LAUNCH_Q(RMIN, MINW)                                                                                  \
@@ -724,9 +725,14 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // is the fastest (measured).  11 = that batch kernel for every launch.
   // 16-19 = k_traverse_q (four lanes per ray; measured slower) for every launch
   const bool quad = cull && s.q_wide != nullptr && g.opt_kernel >= 16 && g.opt_kernel <= 19;
-  const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;
+  const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;  // 20, 21: k_traverse_p with two-round leaf loads
   const bool wide = cull && !quad && ((base && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10) || g.opt_kernel == 14);
   const bool packet = cull && !quad && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
+  // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on
+  // the 1080p frame: 3.79 -> 3.30 ms of traversal (each XCD's L2 then serves one part of the frame).
+  // NOVA_HIP_OPT_TUNE bits 16+ override it for A/B runs (0x100 = all off).
+  A.flags = (g.opt_tune >> 16) != 0 ? static_cast<uint32_t>(g.opt_tune >> 16) & 0xFFu : 0xDu;
   if (quad) rc = launch_traverse_quad(s, A, count);
   else if (packet) {
     // production: node and triangles through the scalar cache; 13 = staged through LDS by a

@@ -90,6 +90,7 @@ struct TraverseArgs {
   uint32_t* spill;                   // stack entries beyond the LDS part: [entry][thread of the grid]
   uint32_t n_tris;
   uint32_t rays_per_wave;            // k_traverse_p: largest number of rays a wave takes from the queue at a time
+  uint32_t flags;                    // bits 0-1 = RayQueue mode, bit 2 = ray kinds interleaved
 };
 
 // Per-leaf cull slack (see the header comment).  For a ray with |origin| <= R and a hit inside
@@ -174,6 +175,32 @@ NV_DEV bool woop(const RayState& r, HitState& h, int index, float4 mx, float4 my
   float oz = fma_(mz.x, r.o.x, fma_(mz.y, r.o.y, fma_(mz.z, r.o.z, mz.w)));
   float dz = fma_(mz.x, r.d.x, fma_(mz.y, r.d.y, mz.z * r.d.z));
   float t = -oz / dz;
+  if (t < 0.0f || !__builtin_isfinite(t)) return false;
+  if (t >= h.t) {
+    if (!(t == h.t && h.id >= 0 && index < h.id)) return false;
+  }
+  float ox = fma_(mx.x, r.o.x, fma_(mx.y, r.o.y, fma_(mx.z, r.o.z, mx.w)));
+  float oy = fma_(my.x, r.o.x, fma_(my.y, r.o.y, fma_(my.z, r.o.z, my.w)));
+  float dx = fma_(mx.x, r.d.x, fma_(mx.y, r.d.y, mx.z * r.d.z));
+  float dy = fma_(my.x, r.d.x, fma_(my.y, r.d.y, my.z * r.d.z));
+  float u = fma_(t, dx, ox);
+  float v = fma_(t, dy, oy);
+  float w = (1.0f - u) - v;
+  if (w < 0.0f || u < 0.0f || v < 0.0f) return false;
+  h.t = t;
+  h.u = u;
+  h.v = v;
+  h.id = index;
+  return true;
+}
+
+// woop() in two parts: the distance from the z row alone, then the rest (same operations, same order)
+NV_DEV float woop_t(const RayState& r, float4 mz) {
+  float oz = fma_(mz.x, r.o.x, fma_(mz.y, r.o.y, fma_(mz.z, r.o.z, mz.w)));
+  float dz = fma_(mz.x, r.d.x, fma_(mz.y, r.d.y, mz.z * r.d.z));
+  return -oz / dz;
+}
+NV_DEV bool woop_uv(const RayState& r, HitState& h, int index, float t, float4 mx, float4 my) {
   if (t < 0.0f || !__builtin_isfinite(t)) return false;
   if (t >= h.t) {
     if (!(t == h.t && h.id >= 0 && index < h.id)) return false;
@@ -430,20 +457,40 @@ constexpr uint32_t kSubQueueStride = 32; // u32 words between heads (128 bytes)
 
 struct RayQueue {
   uint32_t total, grab, per, q, q_tried, w_next, w_end;
+  uint32_t nq, mode, xcd, wave_seq;
   bool dry;
-  NV_DEV void init(uint32_t total_, uint32_t grab_) {
+  // Sub-queue tried after `t` failures.  mode 0: neighbours of the wave's own number.  The other
+  // modes use that work-groups are dealt round-robin over the 8 XCDs (XCD = blockIdx.x % 8), so that
+  // each XCD's L2 sees the rays of one part of the ray array (= of the frame: rays are stored in
+  // pixel-tile order): 1 = sub-queues k with k % 8 == XCD first; 2 = the 8 consecutive sub-queues
+  // 8 * XCD .. 8 * XCD + 7 first; 3 = one sub-queue per XCD (8 heads in all).
+  NV_DEV uint32_t pick(uint32_t t) const {
+    switch (mode) {
+      case 1: return (xcd + 8u * ((wave_seq + t) & 7u) + (t >> 3)) % kSubQueues;
+      case 2: return 8u * ((xcd + (t >> 3)) & 7u) + ((wave_seq + t) & 7u);
+      case 3: return (xcd + t) & 7u;
+      default: return (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) + t) % kSubQueues;
+    }
+  }
+  NV_DEV void init(uint32_t total_, uint32_t grab_, uint32_t mode_ = 0) {
     total = total_;
     grab = grab_;
-    per = (((total + kSubQueues - 1u) / kSubQueues) + 63u) & ~63u;
-    q = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kSubQueues;
+    mode = mode_;
+    nq = mode == 3 ? 8u : kSubQueues;
+    per = (((total + nq - 1u) / nq) + 63u) & ~63u;
+    xcd = blockIdx.x & 7u;
+    wave_seq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (mode_ & 16u) wave_seq = blockIdx.x >> 3; // A/B: the waves of a work-group share a sub-queue
+    mode &= 3u;
     q_tried = 0;
+    q = pick(0);
     w_next = w_end = 0;
     dry = (total == 0);
   }
   // makes [w_next, w_end) non-empty, or sets `dry`
   NV_DEV void fill_window(uint32_t* heads, uint32_t lane) {
     if (dry || w_next < w_end) return;
-    while (q_tried < kSubQueues) {
+    while (q_tried < nq) {
       const uint32_t lo = q * per;
       if (lo < total) {
         const uint32_t hi = min(lo + per, total);
@@ -460,8 +507,8 @@ struct RayQueue {
           return;
         }
       }
-      q = (q + 1u) % kSubQueues;
       q_tried++;
+      q = pick(q_tried);
     }
     dry = true;
   }
@@ -729,7 +776,7 @@ NV_DEV unsigned long long hit_key(const HitState& h) {
                    : ~0ull;
 }
 
-template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK>
+template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK, bool LAZY = false, int TPS = kTrisPerStep>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   __shared__ uint32_t lds_stack[4][SLDS][64];
   // FORK: records of the rays that were split among several lanes of the wave (index = the lane
@@ -759,7 +806,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   // A launch with few rays is latency-bound (the chip is nearly empty and a wave lasts as long as
   // its longest ray), so the grab shrinks until every wave of the grid gets some rays.
   RayQueue Q;
-  Q.init(total, min(A.rays_per_wave, max(2u, total / (gridDim.x * 4u))));
+  Q.init(total, min(A.rays_per_wave, max(2u, total / (gridDim.x * 4u))), A.flags & 19u);
+  const bool interleave = (A.flags & 4u) != 0;
 
   RayState r = {};
   HitState h = { 0.0f, 0.0f, 0.0f, -1 };
@@ -782,8 +830,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         const uint32_t my_rank = rank_in_mask(idle);
         if (cur == kDone && my_rank < take) {
           const uint32_t w = Q.w_next + my_rank;
-          const uint32_t kind = w / n;
-          const uint32_t j = w - kind * n;
+          uint32_t kind = w / n;
+          uint32_t j = w - kind * n;
+          if (interleave) { // the rays of one path next to each other
+            j = w / A.kinds;
+            kind = w - j * A.kinds;
+          }
           slot = static_cast<size_t>(kind) * A.stride + j;
           const float4 o4 = A.ray_o[slot];
           const float4 d4 = A.ray_d[slot];
@@ -940,20 +992,54 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
       }
     } else {
       if (cur & kLeafBit) {
-        // kTrisPerStep triangles of the leaf per step (all loads in flight together; indices past
+        // TPS triangles of the leaf per step (all loads in flight together; indices past
         // the leaf are clamped into the array and their tests skipped); the leaf's remaining range
         // is kept in `cur`
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
-        float4 tm[kTrisPerStep][3];
+        bool finished = false;
+        if (LAZY) {
+          // Two rounds of loads: the z rows first (they give t), then the x and y rows of the
+          // triangles whose t can still win.  A vector load costs ~17 cycles of the CU's memory
+          // path plus ~0.7 per active lane (scripts/ubench_gather.hip), and most triangles of a
+          // leaf are rejected on t alone, so the second round runs with few lanes.
+          float4 tz[TPS];
 #pragma unroll
-        for (int k = 0; k < kTrisPerStep; k++) {
+          for (int k = 0; k < TPS; k++)
+            tz[k] = A.tris[3 * static_cast<size_t>(min(first + k, A.n_tris - 1u)) + 2];
+          float tt[TPS];
+          uint32_t cm = 0;
+#pragma unroll
+          for (int k = 0; k < TPS; k++) {
+            tt[k] = woop_t(r, tz[k]);
+            // superset of what the in-order tests below can accept (h.t only shrinks)
+            const bool cand = count > static_cast<uint32_t>(k) && !(tt[k] < 0.0f) && __builtin_isfinite(tt[k]) && tt[k] <= h.t;
+            cm |= cand ? (1u << k) : 0u;
+            if (COUNT && count > static_cast<uint32_t>(k)) n_tris++;
+          }
+          // candidates in index order; a lane rarely has more than one
+          while (cm != 0 && !finished) {
+            const uint32_t kc = static_cast<uint32_t>(__builtin_ctz(cm));
+            cm &= cm - 1u;
+            float t = tt[0];
+#pragma unroll
+            for (int k = 1; k < TPS; k++) t = kc == static_cast<uint32_t>(k) ? tt[k] : t;
+            const float4* m = A.tris + 3 * static_cast<size_t>(first + kc);
+            const float4 mx = m[0], my = m[1];
+            if (woop_uv(r, h, static_cast<int>(first + kc), t, mx, my)) {
+              finished = anyhit;
+              far_limit = fma_(h.t, kCullRel, h.t);
+            }
+          }
+        } else {
+        float4 tm[TPS][3];
+#pragma unroll
+        for (int k = 0; k < TPS; k++) {
           const float4* m = A.tris + 3 * static_cast<size_t>(min(first + k, A.n_tris - 1u));
           tm[k][0] = m[0]; tm[k][1] = m[1]; tm[k][2] = m[2];
         }
-        bool finished = false;
 #pragma unroll
-        for (int k = 0; k < kTrisPerStep; k++) {
+        for (int k = 0; k < TPS; k++) {
           if (!finished && count > static_cast<uint32_t>(k)) {
             if (COUNT) n_tris++;
             if (woop(r, h, static_cast<int>(first + k), tm[k][0], tm[k][1], tm[k][2])) {
@@ -962,9 +1048,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
             }
           }
         }
+        }
         if (FORK && forked && h.id >= 0) atomicMin(&rec_key[fam], hit_key(h));
-        if (!finished && count > static_cast<uint32_t>(kTrisPerStep)) {
-          cur = kLeafBit | ((count - kTrisPerStep - 1u) << 24) | (first + kTrisPerStep);
+        if (!finished && count > static_cast<uint32_t>(TPS)) {
+          cur = kLeafBit | ((count - TPS - 1u) << 24) | (first + TPS);
         } else if (!finished && st.sp != 0) {
           cur = st.pop();
         } else {
@@ -1040,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
 
   RayQueue Q;
-  Q.init(total, 64u);
+  Q.init(total, 64u, (A.flags & 8u) ? (A.flags & 3u) : 0u);
   while (true) {
     Q.fill_window(A.queue_head, lane);
     if (Q.dry) break;

@@ -7,7 +7,9 @@ from nova_amd import scene as S, capi
 from nova_amd.raytracer import Raytracer
 from tests.conftest import random_rays
 
-kernels = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,6").split(",")]
+# entries: kernel or kernel:tune (tune = NOVA_HIP_OPT_TUNE: grab size | flags << 16)
+kernels = [tuple(int(y, 0) for y in (x + ":0").split(":")[:2]) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,6").split(",")]
+small = "--no-small" not in sys.argv
 capi.init(0)
 capi.set_option(capi.OPT_TUNE, int(os.environ.get('NOVA_TUNE', '0')))
 ok = True
@@ -18,10 +20,12 @@ def batch(sc, pt, df, kern, trav=0):
     tb, bb = capi.Buffer(sc.triangles), capi.Buffer(sc.bvh)
     ro, rd, hb = capi.Buffer(pt), capi.Buffer(df), capi.Buffer(nbytes=16 * n)
     capi.set_option(capi.OPT_TRAVERSAL, trav)
-    capi.set_option(capi.OPT_TRAVERSE_KERNEL, kern)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, kern[0])
+    capi.set_option(capi.OPT_TUNE, kern[1])
     capi.trace_rays(tb, bb, ro, rd, hb, n)
     capi.set_option(capi.OPT_TRAVERSAL, 0)
     capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
+    capi.set_option(capi.OPT_TUNE, 0)
     return hb.read(np.uint32).reshape(n, 4)
 
 
@@ -35,7 +39,7 @@ scenes = {
 rng = np.random.default_rng(0)
 many = (rng.uniform(-0.3, 0.3, (300, 3, 3)) * [1, 1, 0.001]).reshape(300, 9).astype(np.float32)
 scenes["bigleaf"] = S.build_scene(many)
-for name, sc in scenes.items():
+for name, sc in (scenes.items() if small else []):
     pt, df = random_rays(200000, seed=31, anyhit_every=7, tmax_every=5)
     # axis-parallel directions (zero components, both signs of zero) -> box-pair path inside k_traverse4
     d = df[:, :3].copy()
@@ -49,13 +53,13 @@ for name, sc in scenes.items():
     df[::11, 0] = 0.0
     df[::13, 1] = -0.0
     pt[::19, :3] = 0.0  # origins at 0: -o/d = -0 * inf = NaN on axis-parallel rays
-    walk = batch(sc, pt, df, 0, trav=1)
+    walk = batch(sc, pt, df, (0, 0), trav=1)
     anyhit = (df[:, 3].view(np.uint32) & 1) == 1
     for k in kernels:
         got = batch(sc, pt, df, k)
         same = (got[~anyhit] == walk[~anyhit]).all() and ((got[anyhit, 3].view(np.int32) >= 0) == (walk[anyhit, 3].view(np.int32) >= 0)).all()
         ok &= bool(same)
-        print("%-8s kernel %d vs reference walk: %s (hits %.3f)" % (name, k, same, (walk[:, 3].view(np.int32) >= 0).mean()), flush=True)
+        print("%-8s kernel %s vs reference walk: %s (hits %.3f)" % (name, k, same, (walk[:, 3].view(np.int32) >= 0).mean()), flush=True)
 
 # ---- full size: path tracing on the dragon stand-in ------------------------------------------------
 sc = S.dragon_standin()
@@ -67,7 +71,8 @@ rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
 base = None
 for k in kernels:
-    capi.set_option(capi.OPT_TRAVERSE_KERNEL, k)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, k[0])
+    capi.set_option(capi.OPT_TUNE, k[1])
     rt.kernel_raytrace(3)
     best = None
     for rep in range(3):
@@ -85,9 +90,10 @@ for k in kernels:
         base = img
     same = bool((img == base).all())
     ok &= same
-    print("dragon kernel %d: traverse %.2f ms shade %.2f ms wall %.2f ms -> %.0f Mrays/s; node lines/ray %.1f tris/ray %.1f; bit-equal to first: %s" % (
+    print("dragon kernel %s: traverse %.2f ms shade %.2f ms wall %.2f ms -> %.0f Mrays/s; node lines/ray %.1f tris/ray %.1f; bit-equal to first: %s" % (
         k, best[0], best[1], best[2] * 1e3, rays / best[2] / 1e6, cw["node_visits"] / rays, cw["triangle_tests"] / rays, same), flush=True)
 capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
+capi.set_option(capi.OPT_TUNE, 0)
 
 # ---- incoherent batch on a 2M soup --------------------------------------------------------------
 sc = S.build_scene(S.soup(2_000_000, seed=4))
@@ -97,7 +103,8 @@ tb, bb = capi.Buffer(sc.triangles), capi.Buffer(sc.bvh)
 ro, rd, hb = capi.Buffer(pt), capi.Buffer(df), capi.Buffer(nbytes=16 * n)
 base = None
 for k in kernels:
-    capi.set_option(capi.OPT_TRAVERSE_KERNEL, k)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, k[0])
+    capi.set_option(capi.OPT_TUNE, k[1])
     capi.trace_rays(tb, bb, ro, rd, hb, n)
     capi.reset_counters()
     capi.trace_rays(tb, bb, ro, rd, hb, n)
@@ -107,7 +114,8 @@ for k in kernels:
         base = got
     same = bool((got == base).all())
     ok &= same
-    print("soup2M kernel %d: traverse %.2f ms -> %.0f Mrays/s; bit-equal: %s" % (k, c["traverse_ms"], n / c["traverse_ms"] / 1e3, same), flush=True)
+    print("soup2M kernel %s: traverse %.2f ms -> %.0f Mrays/s; bit-equal: %s" % (k, c["traverse_ms"], n / c["traverse_ms"] / 1e3, same), flush=True)
 capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
+capi.set_option(capi.OPT_TUNE, 0)
 print("ALL OK" if ok else "MISMATCH", flush=True)
 sys.exit(0 if ok else 1)
