@@ -480,14 +480,16 @@ struct RayQueue {
     per = (((total + nq - 1u) / nq) + 63u) & ~63u;
     xcd = blockIdx.x & 7u;
     wave_seq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (mode_ & 16u) wave_seq = blockIdx.x >> 3; // A/B: the waves of a work-group share a sub-queue
-    mode &= 3u;
+    // (tried, no effect: the waves of a work-group, or of a CU by HW_ID, sharing one sub-queue)
     q_tried = 0;
     q = pick(0);
     w_next = w_end = 0;
     dry = (total == 0);
   }
-  // makes [w_next, w_end) non-empty, or sets `dry`
+  // makes [w_next, w_end) non-empty, or sets `dry`.  (Tried and dropped: one vector load that shows
+  // all 64 heads at once, to learn "drained" after one round trip instead of up to 64 — 6-15 %
+  // slower on the 1080p frame: the head lines are hot in L2 and every wave reading all of them
+  // serialises there.)
   NV_DEV void fill_window(uint32_t* heads, uint32_t lane) {
     if (dry || w_next < w_end) return;
     while (q_tried < nq) {
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   // A launch with few rays is latency-bound (the chip is nearly empty and a wave lasts as long as
   // its longest ray), so the grab shrinks until every wave of the grid gets some rays.
   RayQueue Q;
-  Q.init(total, min(A.rays_per_wave, max(2u, total / (gridDim.x * 4u))), A.flags & 19u);
+  Q.init(total, min(A.rays_per_wave, max(2u, total / (gridDim.x * 4u))), A.flags & 3u);
   const bool interleave = (A.flags & 4u) != 0;
 
   RayState r = {};
@@ -1036,6 +1038,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
 #pragma unroll
         for (int k = 0; k < TPS; k++) {
           const float4* m = A.tris + 3 * static_cast<size_t>(min(first + k, A.n_tris - 1u));
+          // (non-temporal loads here were 1.45x slower: the three rows of a triangle share a line,
+          // and without L1 allocation each row is its own L2 request)
           tm[k][0] = m[0]; tm[k][1] = m[1]; tm[k][2] = m[2];
         }
 #pragma unroll
