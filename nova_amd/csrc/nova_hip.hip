@@ -39,6 +39,7 @@ namespace {
 constexpr uint32_t kMaxIterations = 1024; // hard cap on path length in unbounded mode
 constexpr uint32_t kTileSize = 64;
 constexpr size_t kHeadWords = static_cast<size_t>(kSubQueues) * kSubQueueStride; // u32 words of one launch's queue heads
+constexpr size_t kQueueWords = 2048; // >= kMaxIterations + 2 path counters, a multiple of the head stride
 
 #define HIP_TRY(expr)                        \
   do {                                       \
@@ -105,6 +106,7 @@ struct Ctx {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_traverse, ev_camera, ev_shade;
+  hipEvent_t chain_tail = nullptr; // last event recorded on the stream with nothing enqueued after it
   double traverse_ms = 0, camera_ms = 0, shade_ms = 0;
   uint64_t traverse_launches = 0, camera_launches = 0;
   uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
@@ -158,6 +160,8 @@ void touch(const void* p) {
 }
 
 hipEvent_t next_event() {
+  static const bool off = std::getenv("NOVA_HIP_NO_EVENTS") != nullptr; // diagnostics: launches without timing events
+  if (off) return nullptr;
   if (g.ev_used == g.ev_pool.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -166,7 +170,26 @@ hipEvent_t next_event() {
   return g.ev_pool[g.ev_used++];
 }
 
+// Timing spans share their boundary events: the event recorded after one kernel is the start of
+// the next span (half the event records of a pair per kernel: 0.05 ms less per 1080p frame; a span
+// then includes the few microseconds of launch gap before its kernel).
+void span_begin(hipEvent_t* e0) {
+  if (g.chain_tail) {
+    *e0 = g.chain_tail;
+    return;
+  }
+  *e0 = next_event();
+  if (*e0) (void) hipEventRecord(*e0, g.stream);
+}
+hipEvent_t span_end() {
+  hipEvent_t e1 = next_event();
+  if (e1) (void) hipEventRecord(e1, g.stream);
+  g.chain_tail = e1;
+  return e1;
+}
+
 void collect_events() {
+  g.chain_tail = nullptr;
   for (auto& p : g.ev_traverse) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) g.traverse_ms += ms;
@@ -717,8 +740,8 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // The distance cull argues from "hit point inside the leaf box => inside every ancestor's box"
   // (traverse.hpp); a tree whose boxes are not nested gets the reference's own exhaustive walk.
   const bool cull = g.opt_traversal == 0 && s.wide != nullptr, count = g.opt_count_work != 0;
-  hipEvent_t e0 = next_event(), e1 = next_event();
-  if (e0) (void) hipEventRecord(e0, g.stream);
+  hipEvent_t e0 = nullptr;
+  span_begin(&e0);
   int rc;
   // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays —
   // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
@@ -746,7 +769,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
     rc = static_cast<int>(hipGetLastError());
   } else if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
-  if (e1) (void) hipEventRecord(e1, g.stream);
+  hipEvent_t e1 = span_end();
   if (e0 && e1) (coherent ? g.ev_camera : g.ev_traverse).push_back({ e0, e1 });
   g.traverse_launches++;
   if (coherent) g.camera_launches++;
@@ -844,8 +867,9 @@ int nova_hip_init(int device_ordinal) {
   HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
   g.num_cus = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc(&g.d_queues, (kMaxIterations + 2) * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&g.d_heads, kHeadWords * (kMaxIterations + 2) * sizeof(uint32_t)));
+  // one allocation, so that one fill per frame clears both: [kQueueWords counters][queue heads]
+  HIP_TRY(hipMalloc(&g.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t)));
+  g.d_heads = g.d_queues + kQueueWords;
   HIP_TRY(hipMalloc(&g.d_counters, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&g.h_pinned, 64, hipHostMallocDefault));
@@ -1162,7 +1186,14 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   F.max_depth = static_cast<uint32_t>(g.opt_max_depth);
   F.n_active = g.d_queues;
   F.block_counters = g.fb.block_counters;
-  HIP_TRY(hipMemsetAsync(g.d_queues, 0, (kMaxIterations + 2) * sizeof(uint32_t), g.stream));
+  const bool path_tracing = params->path_tracing != 0;
+  const bool nee = path_tracing && num_lights > 0;
+  uint32_t last_it;
+  if (!path_tracing) last_it = 0;
+  else if (F.max_depth != 0) last_it = nee ? F.max_depth : F.max_depth - 1;
+  else last_it = kMaxIterations - 1;
+  // path counters and the queue heads of every iteration: one fill
+  HIP_TRY(hipMemsetAsync(g.d_queues, 0, (kQueueWords + kHeadWords * (last_it + 1)) * sizeof(uint32_t), g.stream));
   const unsigned blocks = (P + 255) / 256;
   const unsigned shade_blocks = (P + kShadeBlock - 1) / kShadeBlock;
   // primary rays = valid pixels of this rank's tiles
@@ -1172,21 +1203,14 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     g.host_primary += static_cast<uint64_t>(w) * hgt;
   }
   {
-    hipEvent_t e0 = next_event(), e1 = next_event();
-    if (e0) (void) hipEventRecord(e0, g.stream);
+    hipEvent_t e0 = nullptr;
+    span_begin(&e0);
     hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, g.stream, F, planes_of(0), g.fb.ray_o[0], g.fb.ray_d[0]);
-    if (e1) (void) hipEventRecord(e1, g.stream);
+    hipEvent_t e1 = span_end();
     if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
   }
   HIP_TRY(hipGetLastError());
 
-  const bool path_tracing = params->path_tracing != 0;
-  const bool nee = path_tracing && num_lights > 0;
-  uint32_t last_it;
-  if (!path_tracing) last_it = 0;
-  else if (F.max_depth != 0) last_it = nee ? F.max_depth : F.max_depth - 1;
-  else last_it = kMaxIterations - 1;
-  HIP_TRY(hipMemsetAsync(g.d_heads, 0, kHeadWords * (last_it + 1) * sizeof(uint32_t), g.stream));
 
   for (uint32_t it = 0; it <= last_it; it++) {
     const int in = it & 1, out = in ^ 1;
@@ -1202,11 +1226,11 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     rc = launch_traverse(*scene, T, it == 0);
     if (rc) return rc;
     {
-      hipEvent_t e0 = next_event(), e1 = next_event();
-      if (e0) (void) hipEventRecord(e0, g.stream);
+      hipEvent_t e0 = nullptr;
+      span_begin(&e0);
       hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(kShadeBlock), 0, g.stream, F, it, planes_of(in), planes_of(out),
                          g.fb.ray_o[in], g.fb.ray_d[in], g.fb.hits, g.fb.ray_o[out], g.fb.ray_d[out]);
-      if (e1) (void) hipEventRecord(e1, g.stream);
+      hipEvent_t e1 = span_end();
       if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
     }
     HIP_TRY(hipGetLastError());
@@ -1214,6 +1238,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     if (F.max_depth == 0 && path_tracing && it >= 3 && (it & 1u)) {
       HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_queues + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
       HIP_TRY(hipStreamSynchronize(g.stream));
+      g.chain_tail = nullptr;
       if (*g.h_pinned == 0) break;
     }
   }
