@@ -257,7 +257,7 @@ def _irregular_rays(n, seed):
 
 
 @pytest.mark.parametrize("fixture", ["cornell", "knot_small", "soup50k"])
-@pytest.mark.parametrize("kernel", [0, 6, 11])
+@pytest.mark.parametrize("kernel", [0, 6, 11, 16, 20])  # 16 = four lanes per ray (k_traverse_q), 20 = two-round leaf loads
 def test_axis_parallel_rays_take_the_exact_path(fixture, kernel, request):
     sc = request.getfixturevalue(fixture)
     pt, df = _irregular_rays(100000, seed=31)
@@ -291,6 +291,28 @@ def test_tree_with_boxes_that_are_not_nested_is_walked_like_the_reference(soup50
     for kernel in (0, 6):
         got = _trace(sc.triangles, bvh, pt, df, kernel=kernel)
         assert (got == ref).all()
+
+
+@pytest.mark.parametrize("flags", [0x100, 0x1, 0x2, 0x3, 0x5, 0xD])
+def test_ray_queue_order_does_not_change_results(flags, knot_small):
+    """The ray queue may hand rays to waves in any order (sub-queue mapping per XCD, the three rays of a
+    path adjacent or not: traverse.hpp RayQueue): every frame must be the same bits."""
+    w, h = 256, 192
+    cam = S.Camera(width=w, height=h, **S.DRAGON_CAMERA)
+    p = S.make_scene_params(cam, shading_metallic=0.4, shading_roughness=0.1)
+    rt = Raytracer(0)
+    rt.set_scene(knot_small, p, w, h)
+    capi.set_option(capi.OPT_MAX_DEPTH, 4)
+    rt.kernel_raytrace(7)
+    base = rt.temp_color_img1.read().copy()
+    capi.set_option(capi.OPT_TUNE, flags << 16)
+    try:
+        rt.kernel_raytrace(7)
+        got = rt.temp_color_img1.read()
+    finally:
+        capi.set_option(capi.OPT_TUNE, 0)
+        capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    assert (got.view(np.uint32) == base.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 5000])
