@@ -649,12 +649,13 @@ int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
 }
 
 constexpr int kWideLdsStack = 16;       // LDS stack entries per lane of k_traverse4 (16 KB per block)
-constexpr int kWideBlocksPerCu = 8;
+constexpr int kWideBlocksPerCu = 5; // = the resident work-groups at 5 waves/SIMD (8 was 0-10 % slower on launches below 0.3 M rays)
 
 // k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
 int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   const uint32_t need = std::max(s.stack_need, s.stack_need_wide);
-  const unsigned blocks = static_cast<unsigned>(g.num_cus * kWideBlocksPerCu);
+  const unsigned per_cu = ((g.opt_tune >> 12) & 15) != 0 ? static_cast<unsigned>((g.opt_tune >> 12) & 15) : kWideBlocksPerCu; // A/B
+  const unsigned blocks = static_cast<unsigned>(g.num_cus) * per_cu;
   const size_t threads = static_cast<size_t>(blocks) * 256;
   const size_t words = need > static_cast<uint32_t>(kWideLdsStack) ? (need - kWideLdsStack) * threads : 0;
   if (words > g.spill_words) {
@@ -667,7 +668,7 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   }
   A.wide = s.wide;
   A.spill = g.d_spill;
-  A.rays_per_wave = (g.opt_tune & 0xFFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFFF) : 64u;
+  A.rays_per_wave = (g.opt_tune & 0xFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFF) : 64u;
   const dim3 grid(blocks), block(256);
   if (s.wide != nullptr && g.opt_kernel != 6) {
     // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
@@ -762,6 +763,8 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
     // four-lane vector load instead (A/B: 0.79-0.82 ms vs 0.74-0.78 ms on the 1080p camera rays)
     const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
     if (g.opt_kernel != 13) {
+      // (the wave-uniform stack in registers instead of LDS — select on push, v_readlane on pop — made
+      // no difference: the kernel waits on the scalar loads of nodes, not on its stack)
       if (count) hipLaunchKernelGGL((k_traverse_packet<true, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
       else hipLaunchKernelGGL((k_traverse_packet<false, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
     } else if (count) hipLaunchKernelGGL((k_traverse_packet<true, true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
