@@ -615,29 +615,6 @@ template <int STACK>
 int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
   const int blocks_per_cu = STACK <= 32 ? 4 : 2;
   dim3 grid(static_cast<unsigned>(g.num_cus * blocks_per_cu)), block(256);
-  // opt_kernel: 0 = batch kernel (64 rays per wave per batch; production: fastest measured, see
-  // DESIGN.md "Experiments"); 1..5 = per-lane refill variants kept for A/B runs:
-  // 1 = if-if, refill at >= 24 idle lanes; 2 = while-while; 3..5 = other thresholds
-#define NOVA_LAUNCH_WW(WWF, RMIN)                                                                              \
-  do {                                                                                                         \
-    if (cull) {                                                                                                \
-      if (count) hipLaunchKernelGGL((k_traverse_ww<STACK, true, true, WWF, RMIN>), grid, block, 0, g.stream, A);   \
-      else hipLaunchKernelGGL((k_traverse_ww<STACK, true, false, WWF, RMIN>), grid, block, 0, g.stream, A);        \
-    } else {                                                                                                   \
-      if (count) hipLaunchKernelGGL((k_traverse_ww<STACK, false, true, WWF, RMIN>), grid, block, 0, g.stream, A);  \
-      else hipLaunchKernelGGL((k_traverse_ww<STACK, false, false, WWF, RMIN>), grid, block, 0, g.stream, A);       \
-    }                                                                                                          \
-    return static_cast<int>(hipGetLastError());                                                                \
-  } while (0)
-  switch (g.opt_kernel) {
-    case 1: NOVA_LAUNCH_WW(false, 24);
-    case 2: NOVA_LAUNCH_WW(true, 24);
-    case 3: NOVA_LAUNCH_WW(false, 8);
-    case 4: NOVA_LAUNCH_WW(false, 40);
-    case 5: NOVA_LAUNCH_WW(true, 40);
-    default: break;
-  }
-#undef NOVA_LAUNCH_WW
   if (cull) {
     if (count) hipLaunchKernelGGL((k_traverse<STACK, true, true>), grid, block, 0, g.stream, A);
     else hipLaunchKernelGGL((k_traverse<STACK, true, false>), grid, block, 0, g.stream, A);
@@ -671,7 +648,7 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   A.rays_per_wave = (g.opt_tune & 0xFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFF) : 64u;
   const dim3 grid(blocks), block(256);
   if (s.wide != nullptr && g.opt_kernel != 6) {
-    // persistent lanes; 7 = refill at 16 idle lanes, 8 = at 8, 9 = at 32
+    // persistent lanes (production); A/B variants: 7, 14, 20
 #define NOVA_LAUNCH_P(RMIN, MINW, FORK, LAZY, TPS)                                                                                   \
     do {                                                                                                                        \
       if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW, FORK, LAZY, TPS>), grid, block, 0, g.stream, A);  \
@@ -679,10 +656,8 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       return static_cast<int>(hipGetLastError());                                                                               \
     } while (0)
     switch (g.opt_kernel) {
-      case 7: NOVA_LAUNCH_P(16, 6, false, false, 3);
-      case 9: NOVA_LAUNCH_P(8, 6, false, false, 3);
-      case 10: NOVA_LAUNCH_P(4, 6, true, false, 3);
-      case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);
+      case 7: NOVA_LAUNCH_P(8, 5, false, false, 3);  // no forking in the drain
+      case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);  // 6 waves/SIMD (spills 5-9 registers)
       case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
       default: NOVA_LAUNCH_P(8, 5, true, false, 3); // 88-94 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9
     }
@@ -750,7 +725,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // 16-19 = k_traverse_q (four lanes per ray; measured slower) for every launch
   const bool quad = cull && s.q_wide != nullptr && g.opt_kernel >= 16 && g.opt_kernel <= 19;
   const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;  // 20, 21: k_traverse_p with two-round leaf loads
-  const bool wide = cull && !quad && ((base && !coherent) || (g.opt_kernel >= 6 && g.opt_kernel <= 10) || g.opt_kernel == 14);
+  const bool wide = cull && !quad && ((base && !coherent) || g.opt_kernel == 6 || g.opt_kernel == 7 || g.opt_kernel == 14);
   const bool packet = cull && !quad && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
   // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
   // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on

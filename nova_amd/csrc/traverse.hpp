@@ -285,166 +285,7 @@ __device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_traverse_ww: EXPERIMENTAL variant (NOVA_HIP_OPT_TRAVERSE_KERNEL 1..5), slower than k_traverse on
-// MI355X as measured (DESIGN.md "Experiments").  Persistent waves, one ray per LANE (not per batch):
-//   * a lane whose ray has finished is refilled from the wave's private chunk of the global ray
-//     queue (one atomic per kChunk rays), so short rays do not leave lanes idle until the longest
-//     ray of a 64-ray batch ends (measured on the batch kernel above: 15 % of VALU lanes active);
-//   * "while-while" control flow: all lanes first walk inner nodes until every live lane holds a
-//     leaf (or has finished), then all leaves are intersected together, so the wave does not
-//     execute the node path and the triangle path on every iteration.
-// Per-ray arithmetic and results are identical to trace_one / k_traverse.
-// ---------------------------------------------------------------------------------------------
 constexpr uint32_t kDone = 0x7FFFFFFFu; // `cur` of a lane without a ray (never a node index)
-constexpr uint32_t kChunk = 256;        // rays a wave reserves per queue atomic
-
-template <int STACK, bool CULL, bool COUNT, bool WW, int REFILL_MIN>
-__global__ __launch_bounds__(256) void k_traverse_ww(TraverseArgs A) {
-  __shared__ uint32_t lds_stack[4][STACK][64];
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t (*stk)[64] = lds_stack[threadIdx.x >> 6];
-  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds;
-  uint32_t n_nodes = 0, n_tris = 0;
-  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
-  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
-
-  // wave-uniform queue window [w_next, w_end)
-  uint32_t w_next = 0, w_end = 0;
-  bool queue_dry = (total == 0);
-
-  RayState r = {};
-  HitState h = { 0.0f, 0.0f, 0.0f, -1 };
-  float slack_scale = 0.0f, far_limit = 0.0f;
-  bool anyhit = false;
-  uint32_t sp = 0, cur = kDone;
-  size_t slot = 0;
-
-  while (true) {
-    // ---- refill lanes that have no ray ---------------------------------------------------------
-    uint64_t idle = __ballot(cur == kDone);
-    // refill only when enough lanes are idle: ray set-up (loads, three divisions) is executed by
-    // the whole wave, so doing it for one or two lanes at a time costs more than it saves
-    while ((__popcll(idle) >= REFILL_MIN || idle == ~0ull) && !(queue_dry && w_next >= w_end)) {
-      if (w_next >= w_end) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.queue_head, kChunk);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= total) {
-          queue_dry = true;
-          break;
-        }
-        w_next = base;
-        w_end = min(base + kChunk, total);
-        if (w_end == total) queue_dry = true;
-      }
-      const uint32_t want = static_cast<uint32_t>(__popcll(idle));
-      const uint32_t take = min(want, w_end - w_next);
-      const uint32_t my_rank = rank_in_mask(idle);
-      if (cur == kDone && my_rank < take) {
-        const uint32_t w = w_next + my_rank;
-        const uint32_t kind = w / n;
-        const uint32_t j = w - kind * n;
-        slot = static_cast<size_t>(kind) * A.stride + j;
-        const float4 o4 = A.ray_o[slot];
-        const float4 d4 = A.ray_d[slot];
-        h = { o4.w, 0.0f, 0.0f, -1 };
-        bool live = !(o4.w < 0.0f);
-        if (live) {
-          r.d = xyz(d4);
-          r.o = fma3(r.d, kRayEpsilon, xyz(o4)); // kernels/types.hpp:16-20
-          r.inv = { 1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z };
-          r.nio = (-r.o) * r.inv;
-          anyhit = (__float_as_uint(d4.w) & 1u) != 0;
-          float tmin, tmax;
-          live = slab(r, rt, rb, tmin, tmax);
-        }
-        if (live) {
-          const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
-          slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
-                        max_(1.0f, o_inf * A.inv_radius);
-          far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
-          sp = 0;
-          cur = 0;
-        } else {
-          A.hits[slot] = make_float4(h.t, 0.0f, 0.0f, __int_as_float(-1));
-        }
-      }
-      w_next += take;
-      idle = __ballot(cur == kDone);
-    }
-    if (__ballot(cur != kDone) == 0) break;
-
-    // ---- walk inner nodes until every live lane holds a leaf or has finished -------------------
-    // WW: loop here until no lane holds an inner node; otherwise one node step per outer iteration
-    bool more = cur < kDone; // inner node references are < kDone; leaves have bit 31
-    while (more) {
-      const Node64* nd = A.nodes + cur;
-      const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
-      if (COUNT) n_nodes++;
-      float tmin0, tmax0, tmin1, tmax1;
-      bool h0 = slab(r, na, nb, tmin0, tmax0);
-      bool h1 = slab(r, nc, ndd, tmin1, tmax1);
-      if (CULL) {
-        const float es = nc.w * slack_scale;
-        h0 = h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
-        h1 = h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
-      }
-      const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
-      if (h0 && h1) {
-        const bool swap = CULL && (tmin1 < tmin0);
-        stk[sp++][lane] = swap ? ref0 : ref1;
-        cur = swap ? ref1 : ref0;
-      } else if (h0) {
-        cur = ref0;
-      } else if (h1) {
-        cur = ref1;
-      } else if (sp != 0) {
-        cur = stk[--sp][lane];
-      } else {
-        A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-        cur = kDone;
-      }
-      more = WW && cur < kDone;
-    }
-
-    // ---- intersect the leaves --------------------------------------------------------------------
-    if (cur & kLeafBit) {
-      const uint32_t first = cur & 0x00FFFFFFu;
-      const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
-      bool finished = false;
-      for (uint32_t i = first; i < first + count; i++) {
-        const float4* m = A.tris + 3 * static_cast<size_t>(i);
-        if (COUNT) n_tris++;
-        if (woop(r, h, static_cast<int>(i), m[0], m[1], m[2])) {
-          if (anyhit) {
-            finished = true;
-            break;
-          }
-          far_limit = fma_(h.t, kCullRel, h.t);
-        }
-      }
-      if (!finished && sp != 0) {
-        cur = stk[--sp][lane];
-      } else {
-        A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-        cur = kDone;
-      }
-    }
-  }
-  if (COUNT) {
-    unsigned long long a = n_nodes, b = n_tris;
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off);
-      b += __shfl_down(b, off);
-    }
-    if (lane == 0) {
-      atomicAdd(&A.work_counters[0], a);
-      atomicAdd(&A.work_counters[1], b);
-    }
-  }
-}
 
 // Ray queue of one launch, as seen by one wave (all members wave-uniform).  The queue is split into
 // kSubQueues heads, one per 128-byte line: 8192 waves taking 64 rays at a time from ONE head

@@ -52,7 +52,7 @@ def gpu_primary_ids(sc, cam_kw, w, h, time, traversal=0, kernel=0):
     ("soup50k", "ids_soup_256.npz", SOUP_CAMERA, 256),
     ("knot_small", "ids_knot_256.npz", S.DRAGON_CAMERA, 256),
 ])
-@pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 1), (0, 2)])
+@pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 6), (0, 11), (0, 16)])
 def test_primary_hit_ids_match_the_golden_vectors(fixture, file, cam, size, traversal, kernel, request):
     sc = request.getfixturevalue(fixture)
     g = golden(file)
