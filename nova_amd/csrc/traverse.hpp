@@ -2,7 +2,7 @@
 // find_intersection / intersects_aabb / intersects_triangle
 // (reference kernels/raytrace.hpp:38-102, kernels/intersection.hpp:14-52).
 //
-// Layout (built by repack_bvh in nova_hip.hip from the reference's FlatBVHNode[]):
+// Layout (built by Packer in bvh_pack.hpp from the reference's FlatBVHNode[]):
 //   * one 64-byte, 64-byte-aligned Node64 per INNER node holding BOTH children's boxes, so one
 //     cache line fetched per step yields two slab tests (the reference fetches a 32-byte node per
 //     box test, dependent on the previous one);
@@ -43,7 +43,7 @@ struct __attribute__((aligned(64))) Node64 {
   float4 d; // child1 box min.xyz, w = unused
 };
 
-// Four-wide node (built at upload by collapsing the box-pair tree, see WideBuilder in nova_hip.hip):
+// Four-wide node (built at upload by collapsing the box-pair tree, see WideBuilder in bvh_pack.hpp):
 // child k's box is component k of lo[axis] / hi[axis].  An unused slot has a NaN box (never hit).
 // Why collapsing is exact: for a ray whose 1/d and -o/d are finite, the slab bounds
 // fma(c, inv, nio) are monotone in the box coordinate c, so a box contained in another has its
@@ -1075,9 +1075,12 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
       act = 0;
       while (sp != 0 && act == 0) {
         --sp;
-        cur = __builtin_amdgcn_readfirstlane(stk[sp][0]);
-        const uint64_t mk = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(stk[sp][1])) |
-                            (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(stk[sp][2])) << 32);
+        cur = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(stk[sp][0]));
+        // readfirstlane returns int: go through uint32_t, or a mask with lane 31 set sign-extends into
+        // lanes 32-63 (they would then test a popped LEAF's triangles without having passed its box —
+        // found by scripts/gpu_soak.py: 1-3 pixels in 9 of 400 frames)
+        const uint64_t mk = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(stk[sp][1]))) |
+                            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(stk[sp][2]))) << 32);
         act = mk & alive_mask;
       }
     }

@@ -206,6 +206,23 @@ def test_full_size_culled_traversal_equals_the_reference_walk():
     assert rel_rmse(out[0][500:532], ref[500:532]) <= RADIANCE_TOL
 
 
+def test_packet_kernel_keeps_lane_masks_above_lane_31():
+    """Regression (found by scripts/gpu_soak.py): the camera-ray packet kernel rebuilt a popped 64-bit
+    lane mask from two readfirstlane results, and a low word with lane 31 set sign-extended into lanes
+    32-63; those lanes then tested a popped LEAF without having passed its box, and a triangle whose
+    Woop matrix is near-singular accepted a hit there.  The fixture is the minimal failing packet:
+    33 camera rays of the 871 k-triangle stand-in, the victim in lane 32."""
+    g = golden("packet_mask_regression.npz")
+    pt, df = g["point_tmax"], g["dir_flags"]
+    sc = S.dragon_standin()
+    walk = _trace(sc.triangles, sc.bvh, pt, df, traversal=1)
+    ref = oracle().trace_rays(sc, pt, df).view(np.uint32)
+    assert (walk == ref).all()
+    for kernel in (12, 13, 0, 11):  # 12 / 13 = the packet kernel (scalar loads / staged through LDS) for every launch
+        got = _trace(sc.triangles, sc.bvh, pt, df, kernel=kernel)
+        assert (got == ref).all(), kernel
+
+
 def test_incoherent_ray_batch_on_a_large_soup():
     """BASELINE config 4 in miniature (2 M triangles, 4 M rays): culled == exhaustive, bitwise."""
     sc = S.build_scene(S.soup(2_000_000, seed=4))
