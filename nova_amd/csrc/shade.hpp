@@ -381,6 +381,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
           if (!F.params.path_tracing) {
             // kernels/raytrace.hpp:170-177
             color = color + (here_light != -1 ? v3(F.lights[here_light].intensity) : diffuse);
+            if (F.denoise) {
+              // the reference leaves both features uninitialised on this path (kernels/kernels.cu:29-38
+              // writes the locals that trace_ray never set); defined here as zero, like the oracle
+              F.out_albedo[pixel] = make_float4(0.f, 0.f, 0.f, 1.0f);
+              F.out_normal[pixel] = make_float4(0.f, 0.f, 0.f, 1.0f);
+            }
             finished = true;
           } else {
             const V3 normal = shading_normal(F.materials, m, tu, tv, bc);

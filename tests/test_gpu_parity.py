@@ -5,6 +5,8 @@
     culled) traversal must equal the reference walk (fixed order, no culling) ray for ray.
 Bar: triangle ids, hit records and bytes bit-exact; radiance rel-RMSE <= 1e-3 (north_star) — in
 practice 0: host and device share one arithmetic contract (DESIGN.md "Numerics")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -419,3 +421,16 @@ def test_error_behaviour():
     bb3.write(moved)
     capi.trace_rays(tb, bb3, ro, rd, hb, 1000)
     assert (hb.read(np.int32).reshape(-1, 4)[:, 3] == -1).all() and (first.view(np.int32).reshape(-1, 4)[:, 3] >= 0).any()
+
+
+def test_random_configurations_against_the_oracle_bitwise():
+    """A short run of scripts/gpu_soak_oracle.py (the long runs are logged in profiles/): the whole
+    per-sample schedule on random scenes, cameras, odd frame sizes, depth caps, shading defaults,
+    textures, feature images, FXAA, accumulated samples and tile partitions, GPU == oracle bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_soak_oracle.py"), "40", "200"],
+                         cwd=root, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "SOAK OK" in res.stdout
