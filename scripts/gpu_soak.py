@@ -20,7 +20,7 @@ checked_rays = 0
 
 
 def frames(name, sc, w, h, depth, metallic, roughness, dist=(1.2, 3.0)):
-    global bad, checked_pixels
+    global bad, checked_pixels, n_frames
     rt = Raytracer(0)
     first = True
     for f in range(n_frames):
@@ -103,6 +103,17 @@ batches("cornell", sc, 500_000, 6)
 sc = S.build_scene(S.soup(500_000, seed=9, edge=0.03))
 frames("soup 500k", sc, 640, 360, 4, 0.2, 0.3)
 batches("soup 500k", sc, 1_000_000, 6)
+# degenerate trees: one triangle; 300 coplanar triangles in one leaf (chained 128-triangle chunks)
+batches("one triangle", S.build_scene(np.float32([[-0.5, -0.5, 0, 0.5, -0.5, 0, 0, 0.6, 0]])), 200_000, 3)
+many = (np.random.default_rng(0).uniform(-0.3, 0.3, (300, 3, 3)) * [1, 1, 0.001]).reshape(300, 9).astype(np.float32)
+batches("big leaf", S.build_scene(many), 200_000, 3)
+# cameras far outside the scene box (cull slack scaled by |origin| / radius) and inside the geometry
+sc = S.dragon_standin(200, 200)
+n_keep = n_frames
+n_frames = max(4, n_frames // 4)
+frames("knot 80k, far cameras", sc, 640, 360, 5, 0.4, 0.1, dist=(4.0, 40.0))
+frames("knot 80k, cameras inside", sc, 640, 360, 5, 0.9, 0.05, dist=(0.0, 0.9))
+n_frames = n_keep
 print("checked %d pixels and %d rays; failing frames/batches: %d" % (checked_pixels, checked_rays, bad))
 print("SOAK OK" if bad == 0 else "SOAK FAILED")
 sys.exit(0 if bad == 0 else 1)
