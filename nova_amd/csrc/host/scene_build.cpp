@@ -109,7 +109,10 @@ struct Builder {
     best.cost = node->box.cost(n);
 
     const V3 start = node->box.bottom, stop = node->box.top;
-    const V3 step = (stop - start) * (1.0f / static_cast<float>(num_bins));
+    // bvh.cpp:152: glm's vec3 / float divides each component (include/glm/detail/type_vec3.inl:715)
+    const float fbins = static_cast<float>(num_bins);
+    const V3 d = stop - start;
+    const V3 step = { d.x / fbins, d.y / fbins, d.z / fbins };
     const V3 inv_step = { 1.0f / step.x, 1.0f / step.y, 1.0f / step.z };
 
     std::vector<uint32_t> bin_of(static_cast<size_t>(n) * 3);
