@@ -244,6 +244,26 @@ typedef struct {
 int nova_hip_get_counters(nova_hip_counters* out);
 int nova_hip_reset_counters(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * BVH construction on the device.  Replaces BVH::build
+ * (src/bvh/bvh.cpp:17-249: binned SAH, 1024/(depth+1) bins, stable split, DFS flattening with the
+ * larger child first) and the TriangleData loop of IntersectableManager::build
+ * (src/intersectables/intersectable_manager.cpp:129-145).  Same tree, node for node.
+ * vertices: num_triangles x (v1 v2 v3) floats, HOST memory, in the order the caller's TriangleMetaData
+ * is in.  Outputs are HOST arrays: bvh_out[bvh_capacity >= nova_hip_bvh_max_nodes(num_triangles)],
+ * triangles_out[num_triangles] (leaf order), order_out[i] = input index of output triangle i (to
+ * permute the meta data with).  At most 2^24 triangles: FlatBVHNode keeps offsets in floats.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  float device_ms;         /* device time of the build, without the copies in and out */
+  uint32_t levels;         /* tree depth */
+  uint64_t peak_bin_bytes; /* largest per-level bin storage */
+} nova_hip_build_stats;
+uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles);
+int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
+                       uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
+                       uint32_t* order_out, nova_hip_build_stats* stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

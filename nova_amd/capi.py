@@ -102,7 +102,10 @@ def load() -> ctypes.CDLL:
         "nova_hip_get_option": [ctypes.c_int, vp],
         "nova_hip_get_counters": [vp],
         "nova_hip_reset_counters": [],
+        "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
     }
+    lib.nova_hip_bvh_max_nodes.restype = u64
+    lib.nova_hip_bvh_max_nodes.argtypes = [u64]
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -285,3 +288,27 @@ def trace_rays(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Bu
                num_rays: int):
     check(load().nova_hip_trace_rays(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
                                      hits.ptr, num_rays))
+
+
+class BuildStats(ctypes.Structure):
+    _fields_ = [("device_ms", ctypes.c_float), ("levels", ctypes.c_uint32), ("peak_bin_bytes", ctypes.c_uint64)]
+
+
+def build_bvh(verts: np.ndarray):
+    """BVH::build + the TriangleData loop on the device (include/nova_hip.h: nova_hip_build_bvh).
+    verts: float32 [n, 9] or [n, 3, 3].  Returns (bvh BVH_NODE[n_nodes], triangles float32[n, 12],
+    order uint32[n], stats dict)."""
+    from .scene import BVH_NODE
+    lib = load()
+    v = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+    n = v.shape[0]
+    cap = int(lib.nova_hip_bvh_max_nodes(n)) if n else 1
+    bvh = np.zeros(cap, BVH_NODE)
+    tris = np.zeros((n, 12), np.float32)
+    order = np.zeros(n, np.uint32)
+    n_nodes = ctypes.c_uint64(0)
+    stats = BuildStats()
+    check(lib.nova_hip_build_bvh(v.ctypes.data, n, bvh.ctypes.data, cap, ctypes.byref(n_nodes), tris.ctypes.data,
+                                 order.ctypes.data, ctypes.byref(stats)))
+    return bvh[: n_nodes.value].copy(), tris, order, {"device_ms": stats.device_ms, "levels": stats.levels,
+                                                     "peak_bin_bytes": stats.peak_bin_bytes}

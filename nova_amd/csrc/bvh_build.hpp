@@ -1,0 +1,746 @@
+// GPU construction of Nova's BVH: the tree BVH::build makes (reference src/bvh/bvh.cpp:17-249 — binned
+// SAH, bins = 1024/(depth+1), stable split on the bin index, DFS pre-order flattening with the
+// larger-surface-area child first) and the Woop TriangleData of IntersectableManager::build
+// (src/intersectables/intersectable_manager.cpp:129-145), built level by level on the device.
+//
+// The result is the SAME tree, node for node and triangle for triangle: every quantity the builder
+// decides on is either an integer (bin counts), a min/max of input coordinates (boxes: exact in any
+// order) or a float expression evaluated per node / per split with the operation order of the source
+// (-ffp-contract=off, correctly rounded division and square root).  The only freedom is the sign of a
+// zero box coordinate (std::max keeps the first of -0/+0, an atomic max keeps +0); it compares equal
+// and no later result depends on it.
+//
+// Level-synchronous: all nodes of one depth are binned, evaluated and split together.
+//   k_bin        one lane per triangle position: bin index on 3 axes, counts and boxes by atomics
+//   k_sah        one lane per (node, axis): suffix boxes, prefix boxes, cost of every split
+//   k_choose     one lane per node: best axis, child records
+//   scan + k_scatter   stable partition of every splitting node's segment at once
+// then sizes bottom-up, DFS indices top-down, and one pass that writes nodes, order and matrices.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "nova_hip.h"
+
+namespace bvhb {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMinTrianglesPerLeaf = 8; // src/constants.hpp:31
+constexpr float kMaxBins = 1024.0f;          // src/constants.hpp:32
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct BNode {
+  float top[3], bot[3];
+  uint32_t begin, end;
+  uint32_t left, right; // child node ids; left == 0: leaf
+  uint32_t slot;        // index among the nodes of its level that are being split, or kNone
+  uint32_t size;        // nodes in the subtree
+};
+
+struct Bin { // all-zero = empty
+  uint32_t count;
+  uint32_t mx[3]; // enc(max)
+  uint32_t mn[3]; // ~enc(min)
+};
+
+struct Slot {
+  uint32_t node;
+  uint32_t n;
+  float start[3], inv[3];
+  uint32_t axis_mask; // bit a: axis a is wide enough to be split (bvh.cpp:169)
+};
+
+struct AxisBest {
+  float cost;
+  uint32_t index, left_n;
+  float ltop[3], lbot[3], rtop[3], rbot[3];
+  int32_t axis; // -1: none
+};
+
+struct Choice {
+  int32_t axis;
+  uint32_t index, left_n, child; // child = id of the left child (right = child + 1)
+};
+
+// monotone float -> uint map: a < b  <=>  enc(a) < enc(b)
+__device__ __forceinline__ uint32_t enc(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float dec(uint32_t e) {
+  uint32_t u = e ^ ((e & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu);
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float dec_max(uint32_t e) { return e == 0 ? -kFltMax : dec(e); }
+__device__ __forceinline__ float dec_min(uint32_t e) { return e == 0 ? kFltMax : dec(~e); }
+__device__ __forceinline__ void raise(uint32_t* p, uint32_t v) {
+  if (*reinterpret_cast<volatile uint32_t*>(p) < v) atomicMax(p, v);
+}
+
+struct Box3 {
+  float top[3], bot[3];
+};
+// AABB::grow (src/intersectables/aabb.hpp): max / min as std::max / std::min pick
+__device__ __forceinline__ void grow(Box3& a, const Box3& b) {
+  for (int i = 0; i < 3; i++) {
+    a.top[i] = (a.top[i] < b.top[i]) ? b.top[i] : a.top[i];
+    a.bot[i] = (b.bot[i] < a.bot[i]) ? b.bot[i] : a.bot[i];
+  }
+}
+// AABB::get_surface_area / get_cost
+__device__ __forceinline__ float surface_area(const float* top, const float* bot) {
+  const float dx = top[0] - bot[0], dy = top[1] - bot[1], dz = top[2] - bot[2];
+  return (dx * dy + dy * dz + dz * dx) * 2.0f;
+}
+__device__ __forceinline__ float cost(const float* top, const float* bot, uint32_t n) {
+  return surface_area(top, bot) * static_cast<float>(n);
+}
+__device__ __forceinline__ Box3 load_bin(const Bin& b) {
+  Box3 r;
+  for (int i = 0; i < 3; i++) {
+    r.top[i] = dec_max(b.mx[i]);
+    r.bot[i] = dec_min(b.mn[i]);
+  }
+  return r;
+}
+
+// ---- triangle bounds and the root box -------------------------------------------------------------
+// tbox[2 i] = (max xyz, -), tbox[2 i + 1] = (min xyz, -)   (Triangle::get_bounds)
+__global__ void k_tri_bounds(const float* __restrict__ verts, uint32_t n, float4* __restrict__ tbox,
+                             uint32_t* __restrict__ root /* 3 enc(max), 3 ~enc(min) */,
+                             uint32_t* __restrict__ order, uint32_t* __restrict__ node_of) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = verts + 9ull * i;
+  float top[3], bot[3];
+  for (int a = 0; a < 3; a++) {
+    const float v1 = p[a], v2 = p[3 + a], v3 = p[6 + a];
+    const float m23 = (v2 < v3) ? v3 : v2, n23 = (v3 < v2) ? v3 : v2;
+    top[a] = (v1 < m23) ? m23 : v1;
+    bot[a] = (n23 < v1) ? n23 : v1;
+  }
+  tbox[2ull * i] = make_float4(top[0], top[1], top[2], 0.0f);
+  tbox[2ull * i + 1] = make_float4(bot[0], bot[1], bot[2], 0.0f);
+  order[i] = i;
+  node_of[i] = 0;
+  for (int a = 0; a < 3; a++) {
+    raise(root + a, enc(top[a]));
+    raise(root + 3 + a, ~enc(bot[a]));
+  }
+}
+
+__global__ void k_root(const uint32_t* __restrict__ root, uint32_t n, BNode* __restrict__ nodes) {
+  BNode nd;
+  for (int a = 0; a < 3; a++) {
+    nd.top[a] = dec_max(root[a]);
+    nd.bot[a] = dec_min(root[3 + a]);
+  }
+  nd.begin = 0;
+  nd.end = n;
+  nd.left = nd.right = 0;
+  nd.slot = kNone;
+  nd.size = 1;
+  nodes[0] = nd;
+}
+
+// ---- exclusive scan of u32 (three passes; the block sums of up to 2^24 items fit one block's loop) ----
+constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t v) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// exclusive prefix of `v` over the block; *total = block sum.  blockDim.x == kScanBlock
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wsum[kScanBlock / 64];
+  const uint32_t inc = wave_inclusive(v);
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  __syncthreads(); // wsum may still be read by the previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+  for (uint32_t i = 0; i < kScanBlock / 64; i++) {
+    if (i < w) base += wsum[i];
+    sum += wsum[i];
+  }
+  *total = sum;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_reduce(const uint32_t* __restrict__ in, uint32_t n,
+                                                             uint32_t* __restrict__ block_sums) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t s = 0;
+  for (uint32_t j = 0; j < kScanItems; j++)
+    if (base + j < n) s += in[base + j];
+  uint32_t total;
+  (void) block_exclusive(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one block: block_sums -> exclusive prefix in place; grand total to *total
+__global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
+                                                           uint32_t* __restrict__ total) {
+  uint32_t carry = 0;
+  for (uint32_t start = 0; start < nb; start += kScanBlock) {
+    const uint32_t i = start + threadIdx.x;
+    const uint32_t v = i < nb ? block_sums[i] : 0u;
+    uint32_t sum;
+    const uint32_t ex = block_exclusive(v, &sum);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += sum;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
+                                                            const uint32_t* __restrict__ block_sums,
+                                                            uint32_t* __restrict__ out) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t v[kScanItems], s = 0;
+  for (uint32_t j = 0; j < kScanItems; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0u;
+    s += v[j];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive(s, &total) + block_sums[blockIdx.x];
+  for (uint32_t j = 0; j < kScanItems; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+// ---- one level ----------------------------------------------------------------------------------------
+// flag[i] = 1 when node ls + i is to be split at this level (bvh.cpp:137-148)
+__global__ void k_level_flags(const BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
+                              uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const BNode& nd = nodes[ls + i];
+  flag[i] = (nd.end - nd.begin > kMinTrianglesPerLeaf) ? 1u : 0u;
+}
+
+__global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, const uint32_t* __restrict__ flag,
+                             const uint32_t* __restrict__ slot_of, uint32_t num_bins, Slot* __restrict__ slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  BNode& nd = nodes[ls + i];
+  if (!flag[i]) {
+    nd.slot = kNone;
+    return;
+  }
+  const uint32_t s = slot_of[i];
+  nd.slot = s;
+  Slot sl;
+  sl.node = ls + i;
+  sl.n = nd.end - nd.begin;
+  sl.axis_mask = 0;
+  const float fbins = static_cast<float>(num_bins);
+  for (int a = 0; a < 3; a++) {
+    const float step = (nd.top[a] - nd.bot[a]) / fbins; // bvh.cpp:152
+    sl.start[a] = nd.bot[a];
+    sl.inv[a] = 1.0f / step;                            // bvh.cpp:153
+    if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) sl.axis_mask |= 1u << a; // bvh.cpp:169
+  }
+  slots[s] = sl;
+}
+
+// bvh.cpp:161-162: min(uvec3((center - bin_start) * inv_bin_step), num_splits)
+__device__ __forceinline__ uint32_t bin_index(float c, float start, float inv, uint32_t num_splits) {
+  const float f = (c - start) * inv;
+  const uint32_t b = (f > 0.0f) ? static_cast<uint32_t>(fminf(f, 4.0e9f)) : 0u;
+  return b < num_splits ? b : num_splits;
+}
+
+__global__ void k_bin(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
+                      const BNode* __restrict__ nodes, uint32_t ls, const Slot* __restrict__ slots,
+                      const float4* __restrict__ tbox, uint32_t num_bins, Bin* __restrict__ bins) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t nd = node_of[k];
+  if (nd < ls) return;
+  const uint32_t s = nodes[nd].slot;
+  if (s == kNone) return;
+  const Slot& sl = slots[s];
+  const uint32_t t = order[k];
+  const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
+  const float tp[3] = { top.x, top.y, top.z }, bt[3] = { bot.x, bot.y, bot.z };
+  uint32_t et[3], eb[3];
+  for (int a = 0; a < 3; a++) {
+    et[a] = enc(tp[a]);
+    eb[a] = ~enc(bt[a]);
+  }
+  for (int a = 0; a < 3; a++) {
+    if (!(sl.axis_mask >> a & 1u)) continue;
+    const float c = (tp[a] + bt[a]) * 0.5f; // AABB::get_center
+    const uint32_t b = bin_index(c, sl.start[a], sl.inv[a], num_bins - 1);
+    Bin* bin = bins + (static_cast<size_t>(s) * 3 + a) * num_bins + b;
+    atomicAdd(&bin->count, 1u);
+    for (int j = 0; j < 3; j++) {
+      raise(&bin->mx[j], et[j]);
+      raise(&bin->mn[j], eb[j]);
+    }
+  }
+}
+
+// bvh.cpp:54-105 for one (node, axis)
+__global__ void k_sah(const Slot* __restrict__ slots, uint32_t n_slots, uint32_t num_bins,
+                      const Bin* __restrict__ bins, Box3* __restrict__ right_bounds, AxisBest* __restrict__ best_out) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_slots * 3) return;
+  const uint32_t s = id / 3, axis = id % 3;
+  const Slot& sl = slots[s];
+  AxisBest best;
+  best.cost = kFltMax;
+  best.index = 0;
+  best.left_n = 0;
+  best.axis = -1;
+  for (int i = 0; i < 3; i++) best.ltop[i] = best.lbot[i] = best.rtop[i] = best.rbot[i] = 0.0f;
+  if (sl.axis_mask >> axis & 1u) {
+    const Bin* b = bins + static_cast<size_t>(id) * num_bins;
+    Box3* rb = right_bounds + static_cast<size_t>(id) * num_bins;
+    Box3 acc = load_bin(b[num_bins - 1]);
+    rb[num_bins - 1] = acc;
+    for (int32_t i = static_cast<int32_t>(num_bins) - 2; i >= 0; i--) {
+      grow(acc, load_bin(b[i]));
+      rb[i] = acc;
+    }
+    Box3 left = load_bin(b[0]);
+    uint32_t left_n = b[0].count;
+    const uint32_t num_splits = num_bins - 1;
+    for (uint32_t split = 0; split < num_splits; split++) {
+      const uint32_t right_n = sl.n - left_n;
+      if (left_n > 2 && right_n > 2) {
+        // the reference pairs left_bounds[s] with right_bounds[s] (bvh.cpp:77-81)
+        const Box3 right = rb[split];
+        const float total = cost(left.top, left.bot, left_n) + cost(right.top, right.bot, right_n);
+        if (!(best.cost < total)) {
+          best.cost = total;
+          best.index = split;
+          best.left_n = left_n;
+          best.axis = static_cast<int32_t>(axis);
+          for (int i = 0; i < 3; i++) {
+            best.ltop[i] = left.top[i];
+            best.lbot[i] = left.bot[i];
+            best.rtop[i] = right.top[i];
+            best.rbot[i] = right.bot[i];
+          }
+        }
+      }
+      grow(left, load_bin(b[split + 1]));
+      left_n += b[split + 1].count;
+    }
+  }
+  best_out[id] = best;
+}
+
+// bvh.cpp:141-142, 184-190: the best of the node's own cost and the three axes, later wins a tie
+__global__ void k_choose(const Slot* __restrict__ slots, uint32_t n_slots, const BNode* __restrict__ nodes,
+                         const AxisBest* __restrict__ axis_best, Choice* __restrict__ choice,
+                         uint32_t* __restrict__ split_flag) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const Slot& sl = slots[s];
+  const BNode& nd = nodes[sl.node];
+  float best_cost = cost(nd.top, nd.bot, sl.n);
+  Choice c;
+  c.axis = -1;
+  c.index = 0;
+  c.left_n = 0;
+  c.child = 0;
+  for (int a = 0; a < 3; a++) {
+    const AxisBest& ab = axis_best[s * 3 + a];
+    if (ab.axis < 0) continue;
+    if (!(best_cost < ab.cost)) {
+      best_cost = ab.cost;
+      c.axis = a;
+      c.index = ab.index;
+      c.left_n = ab.left_n;
+    }
+  }
+  choice[s] = c;
+  split_flag[s] = c.axis >= 0 ? 1u : 0u;
+}
+
+// bvh.cpp:107-118: the two child records
+__global__ void k_make_children(const Slot* __restrict__ slots, uint32_t n_slots, BNode* __restrict__ nodes,
+                                const AxisBest* __restrict__ axis_best, Choice* __restrict__ choice,
+                                const uint32_t* __restrict__ split_rank, uint32_t level_end) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  Choice& c = choice[s];
+  if (c.axis < 0) return;
+  BNode& nd = nodes[slots[s].node];
+  const AxisBest& ab = axis_best[s * 3 + c.axis];
+  const uint32_t child = level_end + 2 * split_rank[s];
+  BNode l, r;
+  for (int i = 0; i < 3; i++) {
+    l.top[i] = ab.ltop[i];
+    l.bot[i] = ab.lbot[i];
+    r.top[i] = ab.rtop[i];
+    r.bot[i] = ab.rbot[i];
+  }
+  l.begin = nd.begin;
+  l.end = nd.begin + c.left_n;
+  r.begin = l.end;
+  r.end = nd.end;
+  l.left = l.right = r.left = r.right = 0;
+  l.slot = r.slot = kNone;
+  l.size = r.size = 1;
+  nodes[child] = l;
+  nodes[child + 1] = r;
+  nd.left = child;
+  nd.right = child + 1;
+  c.child = child;
+}
+
+// goes_left[k] = 1 when position k moves into the left child (bvh.cpp:120-128)
+__global__ void k_goes_left(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
+                            const BNode* __restrict__ nodes, uint32_t ls, const Slot* __restrict__ slots,
+                            const Choice* __restrict__ choice, const float4* __restrict__ tbox, uint32_t num_bins,
+                            uint32_t* __restrict__ goes_left) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t f = 0;
+  const uint32_t nd = node_of[k];
+  if (nd >= ls) {
+    const uint32_t s = nodes[nd].slot;
+    if (s != kNone) {
+      const Choice c = choice[s];
+      if (c.axis >= 0) {
+        const Slot& sl = slots[s];
+        const uint32_t t = order[k];
+        const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
+        const float tp = c.axis == 0 ? top.x : (c.axis == 1 ? top.y : top.z);
+        const float bt = c.axis == 0 ? bot.x : (c.axis == 1 ? bot.y : bot.z);
+        const float ctr = (tp + bt) * 0.5f;
+        f = bin_index(ctr, sl.start[c.axis], sl.inv[c.axis], num_bins - 1) <= c.index ? 1u : 0u;
+      }
+    }
+  }
+  goes_left[k] = f;
+}
+
+// stable split of every splitting node's segment (left part in order, then right part in order)
+__global__ void k_scatter(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
+                          const BNode* __restrict__ nodes, uint32_t ls, const Choice* __restrict__ choice,
+                          const uint32_t* __restrict__ goes_left, const uint32_t* __restrict__ left_before,
+                          uint32_t* __restrict__ order_out, uint32_t* __restrict__ node_of_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t nd = node_of[k];
+  uint32_t pos = k, owner = nd;
+  if (nd >= ls) {
+    const BNode& node = nodes[nd];
+    if (node.slot != kNone) {
+      const Choice c = choice[node.slot];
+      if (c.axis >= 0) {
+        const uint32_t l = left_before[k] - left_before[node.begin];
+        if (goes_left[k]) {
+          pos = node.begin + l;
+          owner = c.child;
+        } else {
+          pos = node.begin + c.left_n + (k - node.begin - l);
+          owner = c.child + 1;
+        }
+      }
+    }
+  }
+  order_out[pos] = order[k];
+  node_of_out[pos] = owner;
+}
+
+// ---- flattening (bvh.cpp:211-249) --------------------------------------------------------------------
+__global__ void k_sizes(BNode* __restrict__ nodes, uint32_t ls, uint32_t m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  BNode& nd = nodes[ls + i];
+  nd.size = nd.left ? 1u + nodes[nd.left].size + nodes[nd.right].size : 1u;
+}
+
+// flat_index / tri_offset of the children, and the node's own flat record
+__global__ void k_flatten(const BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t* __restrict__ flat_index,
+                          uint32_t* __restrict__ tri_offset, nova_bvh_node* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const BNode& nd = nodes[ls + i];
+  const uint32_t me = flat_index[ls + i], toff = tri_offset[ls + i];
+  nova_bvh_node f;
+  f.top_offset_left = { nd.top[0], nd.top[1], nd.top[2], 0.0f };
+  f.bottom_num_right = { nd.bot[0], nd.bot[1], nd.bot[2], 0.0f };
+  if (!nd.left) {
+    f.top_offset_left.w = static_cast<float>(toff);
+    f.bottom_num_right.w = -static_cast<float>(nd.end - nd.begin);
+  } else {
+    uint32_t first = nd.left, second = nd.right;
+    const BNode& l = nodes[first];
+    const BNode& r = nodes[second];
+    if (surface_area(r.top, r.bot) > surface_area(l.top, l.bot)) { // visit the larger child first
+      first = nd.right;
+      second = nd.left;
+    }
+    const BNode& fn = nodes[first];
+    flat_index[first] = me + 1;
+    flat_index[second] = me + 1 + fn.size;
+    tri_offset[first] = toff;
+    tri_offset[second] = toff + (fn.end - fn.begin);
+    f.bottom_num_right.w = static_cast<float>(me + 1 + fn.size);
+  }
+  out[me] = f;
+}
+
+// Triangle order of the flattened tree and the Woop matrices:
+// rows 0..2 of inverse([e1 e2 n-v1 v1; 0 0 0 1]) (intersectable_manager.cpp:129-145), by cofactors
+__global__ void k_emit_triangles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
+                                 const BNode* __restrict__ nodes, const uint32_t* __restrict__ tri_offset,
+                                 const float* __restrict__ verts, uint32_t* __restrict__ tri_order,
+                                 nova_triangle_data* __restrict__ tris) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t leaf = node_of[k];
+  const uint32_t p = tri_offset[leaf] + (k - nodes[leaf].begin);
+  const uint32_t t = order[k];
+  tri_order[p] = t;
+  const float* v = verts + 9ull * t;
+  const float v1[3] = { v[0], v[1], v[2] };
+  float e1[3], e2[3];
+  for (int a = 0; a < 3; a++) {
+    e1[a] = v[3 + a] - v1[a];
+    e2[a] = v[6 + a] - v1[a];
+  }
+  float nr[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+  const float inv_len = 1.0f / sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+  float m[4][4];
+  for (int a = 0; a < 3; a++) {
+    m[a][0] = e1[a];
+    m[a][1] = e2[a];
+    m[a][2] = nr[a] * inv_len - v1[a];
+    m[a][3] = v1[a];
+  }
+  m[3][0] = m[3][1] = m[3][2] = 0.0f;
+  m[3][3] = 1.0f;
+  float cof[4][4];
+  for (int r = 0; r < 4; r++) {
+    for (int c = 0; c < 4; c++) {
+      int rr[3], cc[3];
+      for (int i = 0, q = 0; i < 4; i++)
+        if (i != r) rr[q++] = i;
+      for (int i = 0, q = 0; i < 4; i++)
+        if (i != c) cc[q++] = i;
+      const float mn = m[rr[0]][cc[0]] * (m[rr[1]][cc[1]] * m[rr[2]][cc[2]] - m[rr[1]][cc[2]] * m[rr[2]][cc[1]]) -
+                       m[rr[0]][cc[1]] * (m[rr[1]][cc[0]] * m[rr[2]][cc[2]] - m[rr[1]][cc[2]] * m[rr[2]][cc[0]]) +
+                       m[rr[0]][cc[2]] * (m[rr[1]][cc[0]] * m[rr[2]][cc[1]] - m[rr[1]][cc[1]] * m[rr[2]][cc[0]]);
+      cof[r][c] = ((r + c) & 1) ? -mn : mn;
+    }
+  }
+  const float det = m[0][0] * cof[0][0] + m[0][1] * cof[0][1] + m[0][2] * cof[0][2] + m[0][3] * cof[0][3];
+  const float inv_det = 1.0f / det;
+  nova_triangle_data td;
+  td.x = { cof[0][0] * inv_det, cof[1][0] * inv_det, cof[2][0] * inv_det, cof[3][0] * inv_det };
+  td.y = { cof[0][1] * inv_det, cof[1][1] * inv_det, cof[2][1] * inv_det, cof[3][1] * inv_det };
+  td.z = { cof[0][2] * inv_det, cof[1][2] * inv_det, cof[2][2] * inv_det, cof[3][2] * inv_det };
+  tris[p] = td;
+}
+
+// ---- host driver -------------------------------------------------------------------------------------
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuffer() { (void) hipFree(p); }
+  hipError_t reserve(size_t want) {
+    if (want <= bytes) return hipSuccess;
+    (void) hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    const hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+// upper bound on the nodes of a tree over n triangles: every split leaves more than 2 on each side
+inline uint64_t max_nodes(uint64_t n) {
+  const uint64_t leaves = n / 3 > 1 ? n / 3 : 1;
+  return 2 * leaves - 1;
+}
+
+#define BVHB_TRY(expr)                                   \
+  do {                                                   \
+    const hipError_t e_ = (expr);                        \
+    if (e_ != hipSuccess) return static_cast<int>(e_);   \
+  } while (0)
+
+struct Scanner {
+  DeviceBuffer sums;
+  uint32_t* d_total = nullptr; // device word
+  hipStream_t stream = nullptr;
+  // out[i] = sum of in[0..i); the total lands in *d_total
+  int run(const uint32_t* in, uint32_t n, uint32_t* out) {
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    BVHB_TRY(sums.reserve(static_cast<size_t>(nb) * 4));
+    k_scan_reduce<<<nb, kScanBlock, 0, stream>>>(in, n, sums.as<uint32_t>());
+    k_scan_sums<<<1, kScanBlock, 0, stream>>>(sums.as<uint32_t>(), nb, d_total);
+    k_scan_apply<<<nb, kScanBlock, 0, stream>>>(in, n, sums.as<uint32_t>(), out);
+    return static_cast<int>(hipGetLastError());
+  }
+};
+
+struct Result {
+  uint32_t n_nodes = 0, levels = 0;
+  float device_ms = 0.0f;
+  size_t peak_bin_bytes = 0;
+};
+
+// d_verts: n*9 floats on the device.  d_bvh: room for max_nodes(n) records.  d_tris, d_tri_order: n.
+inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_node* d_bvh,
+                 nova_triangle_data* d_tris, uint32_t* d_tri_order, Result* result) {
+  constexpr uint32_t kB = 256;
+  auto grid = [](uint64_t items) { return static_cast<uint32_t>((items + kB - 1) / kB); };
+  const uint64_t cap = max_nodes(n);
+
+  DeviceBuffer tbox, order[2], node_of[2], nodes, misc, flags, ranks, slots, bins, rbounds, axis_best, choice,
+    gl, gls, flat_index, tri_offset;
+  BVHB_TRY(tbox.reserve(static_cast<size_t>(n) * 32));
+  for (int i = 0; i < 2; i++) {
+    BVHB_TRY(order[i].reserve(static_cast<size_t>(n) * 4));
+    BVHB_TRY(node_of[i].reserve(static_cast<size_t>(n) * 4));
+  }
+  BVHB_TRY(nodes.reserve(cap * sizeof(BNode)));
+  BVHB_TRY(misc.reserve(64));
+  BVHB_TRY(gl.reserve(static_cast<size_t>(n) * 4));
+  BVHB_TRY(gls.reserve(static_cast<size_t>(n) * 4));
+  uint32_t* d_root = misc.as<uint32_t>();      // 6 words
+  uint32_t* d_total = misc.as<uint32_t>() + 8; // scan total
+  uint32_t* h_total = nullptr;
+  BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64));
+  struct Pinned {
+    uint32_t* p;
+    ~Pinned() { (void) hipHostFree(p); }
+  } pinned { h_total };
+  Scanner scan;
+  scan.d_total = d_total;
+  scan.stream = stream;
+  auto read_total = [&](uint32_t* out) -> int {
+    BVHB_TRY(hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, stream));
+    BVHB_TRY(hipStreamSynchronize(stream));
+    *out = *h_total;
+    return 0;
+  };
+
+  hipEvent_t ev0, ev1;
+  BVHB_TRY(hipEventCreate(&ev0));
+  BVHB_TRY(hipEventCreate(&ev1));
+  struct Events {
+    hipEvent_t a, b;
+    ~Events() {
+      (void) hipEventDestroy(a);
+      (void) hipEventDestroy(b);
+    }
+  } events { ev0, ev1 };
+  BVHB_TRY(hipEventRecord(ev0, stream));
+
+  BVHB_TRY(hipMemsetAsync(d_root, 0, 64, stream));
+  k_tri_bounds<<<grid(n), kB, 0, stream>>>(d_verts, n, tbox.as<float4>(), d_root, order[0].as<uint32_t>(),
+                                          node_of[0].as<uint32_t>());
+  k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>());
+
+  std::vector<uint32_t> level_start { 0u };
+  uint32_t ls = 0, le = 1; // nodes of the current level
+  int cur = 0;
+  size_t peak_bins = 0;
+  for (uint32_t depth = 0;; depth++) {
+    level_start.push_back(le);
+    const uint32_t m = le - ls;
+    const uint32_t num_bins = static_cast<uint32_t>(kMaxBins / static_cast<float>(depth + 1)); // bvh.cpp:145
+    if (num_bins <= 1) break;
+    BVHB_TRY(flags.reserve(static_cast<size_t>(m) * 4));
+    BVHB_TRY(ranks.reserve(static_cast<size_t>(m) * 4));
+    k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>());
+    int rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>());
+    if (rc) return rc;
+    uint32_t n_slots = 0;
+    rc = read_total(&n_slots);
+    if (rc) return rc;
+    if (n_slots == 0) break;
+
+    const size_t n_bins = static_cast<size_t>(n_slots) * 3 * num_bins;
+    BVHB_TRY(slots.reserve(static_cast<size_t>(n_slots) * sizeof(Slot)));
+    BVHB_TRY(bins.reserve(n_bins * sizeof(Bin)));
+    BVHB_TRY(rbounds.reserve(n_bins * sizeof(Box3)));
+    BVHB_TRY(axis_best.reserve(static_cast<size_t>(n_slots) * 3 * sizeof(AxisBest)));
+    BVHB_TRY(choice.reserve(static_cast<size_t>(n_slots) * sizeof(Choice)));
+    peak_bins = n_bins * (sizeof(Bin) + sizeof(Box3)) > peak_bins ? n_bins * (sizeof(Bin) + sizeof(Box3)) : peak_bins;
+    k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
+                                            num_bins, slots.as<Slot>());
+    BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
+    k_bin<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls,
+                                     slots.as<Slot>(), tbox.as<float4>(), num_bins, bins.as<Bin>());
+    k_sah<<<grid(static_cast<uint64_t>(n_slots) * 3), kB, 0, stream>>>(slots.as<Slot>(), n_slots, num_bins,
+                                                                      bins.as<Bin>(), rbounds.as<Box3>(),
+                                                                      axis_best.as<AxisBest>());
+    // flags / ranks are reused per slot from here on (n_slots <= m)
+    k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
+                                              choice.as<Choice>(), flags.as<uint32_t>());
+    rc = scan.run(flags.as<uint32_t>(), n_slots, ranks.as<uint32_t>());
+    if (rc) return rc;
+    uint32_t n_split = 0;
+    rc = read_total(&n_split);
+    if (rc) return rc;
+    if (n_split == 0) break;
+    if (static_cast<uint64_t>(le) + 2ull * n_split > cap) return NOVA_HIP_E_BAD_SCENE; // cannot happen
+    k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(),
+                                                     axis_best.as<AxisBest>(), choice.as<Choice>(),
+                                                     ranks.as<uint32_t>(), le);
+    k_goes_left<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n,
+                                           nodes.as<BNode>(), ls, slots.as<Slot>(), choice.as<Choice>(),
+                                           tbox.as<float4>(), num_bins, gl.as<uint32_t>());
+    rc = scan.run(gl.as<uint32_t>(), n, gls.as<uint32_t>());
+    if (rc) return rc;
+    k_scatter<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(),
+                                         ls, choice.as<Choice>(), gl.as<uint32_t>(), gls.as<uint32_t>(),
+                                         order[cur ^ 1].as<uint32_t>(), node_of[cur ^ 1].as<uint32_t>());
+    cur ^= 1;
+    ls = le;
+    le += 2 * n_split;
+  }
+  // level_start[d] .. level_start[d + 1] are the nodes of depth d; the last entry is the node count
+  const uint32_t n_nodes = le;
+  const uint32_t n_levels = static_cast<uint32_t>(level_start.size()) - 1;
+  for (uint32_t d = n_levels; d-- > 0;) {
+    const uint32_t s = level_start[d], m = level_start[d + 1] - s;
+    if (m) k_sizes<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), s, m);
+  }
+  BVHB_TRY(flat_index.reserve(static_cast<size_t>(n_nodes) * 4));
+  BVHB_TRY(tri_offset.reserve(static_cast<size_t>(n_nodes) * 4));
+  BVHB_TRY(hipMemsetAsync(flat_index.p, 0, 4, stream));
+  BVHB_TRY(hipMemsetAsync(tri_offset.p, 0, 4, stream));
+  for (uint32_t d = 0; d < n_levels; d++) {
+    const uint32_t s = level_start[d], m = level_start[d + 1] - s;
+    if (m)
+      k_flatten<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), s, m, flat_index.as<uint32_t>(),
+                                           tri_offset.as<uint32_t>(), d_bvh);
+  }
+  k_emit_triangles<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n,
+                                              nodes.as<BNode>(), tri_offset.as<uint32_t>(), d_verts, d_tri_order, d_tris);
+  BVHB_TRY(hipGetLastError());
+  BVHB_TRY(hipEventRecord(ev1, stream));
+  BVHB_TRY(hipStreamSynchronize(stream));
+  if (result) {
+    result->n_nodes = n_nodes;
+    result->levels = n_levels;
+    result->peak_bin_bytes = peak_bins;
+    BVHB_TRY(hipEventElapsedTime(&result->device_ms, ev0, ev1));
+  }
+  return 0;
+}
+
+} // namespace bvhb

@@ -15,6 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "bvh_build.hpp"
 #include "bvh_pack.hpp"
 #include "image_kernels.hpp"
 #include "nova_hip.h"
@@ -1131,6 +1132,44 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
   touch(hits);
+  return 0;
+}
+
+uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles) { return bvhb::max_nodes(num_triangles); }
+
+int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
+                       uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
+                       uint32_t* order_out, nova_hip_build_stats* stats) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!vertices || !bvh_out || !num_nodes || !triangles_out || !order_out || num_triangles == 0)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  // FlatBVHNode keeps triangle offsets and child indices in floats (src/kernel_types/bvh_node.hpp:13-16)
+  if (num_triangles > (1ull << 24)) return NOVA_HIP_E_TOO_LARGE;
+  if (bvh_capacity < bvhb::max_nodes(num_triangles)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const uint32_t n = static_cast<uint32_t>(num_triangles);
+  bvhb::DeviceBuffer d_verts, d_bvh, d_tris, d_order;
+  HIP_TRY(d_verts.reserve(static_cast<size_t>(n) * 36));
+  HIP_TRY(d_bvh.reserve(bvhb::max_nodes(n) * sizeof(nova_bvh_node)));
+  HIP_TRY(d_tris.reserve(static_cast<size_t>(n) * sizeof(nova_triangle_data)));
+  HIP_TRY(d_order.reserve(static_cast<size_t>(n) * 4));
+  HIP_TRY(hipMemcpyAsync(d_verts.p, vertices, static_cast<size_t>(n) * 36, hipMemcpyHostToDevice, g.stream));
+  bvhb::Result res;
+  rc = bvhb::build(g.stream, d_verts.as<float>(), n, d_bvh.as<nova_bvh_node>(), d_tris.as<nova_triangle_data>(),
+                   d_order.as<uint32_t>(), &res);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(bvh_out, d_bvh.p, static_cast<size_t>(res.n_nodes) * sizeof(nova_bvh_node),
+                         hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipMemcpyAsync(triangles_out, d_tris.p, static_cast<size_t>(n) * sizeof(nova_triangle_data),
+                         hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipMemcpyAsync(order_out, d_order.p, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  *num_nodes = res.n_nodes;
+  if (stats) {
+    stats->device_ms = res.device_ms;
+    stats->levels = res.levels;
+    stats->peak_bin_bytes = res.peak_bin_bytes;
+  }
   return 0;
 }
 
