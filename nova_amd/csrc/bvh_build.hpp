@@ -11,8 +11,14 @@
 // and no later result depends on it.
 //
 // Level-synchronous: all nodes of one depth are binned, evaluated and split together.
-//   k_bin        one lane per triangle position: bin index on 3 axes, counts and boxes by atomics
-//   k_sah        one lane per (node, axis): suffix boxes, prefix boxes, cost of every split
+//   k_bin_sah    one wave per work item = up to `chunk` consecutive triangle positions of ONE node: bin
+//                index per axis, counts and boxes accumulated in LDS.  A node that fits one item (all the
+//                deep levels) is evaluated on the spot, bins never leaving LDS; a larger node's items
+//                add their LDS bins to the node's global bins (one atomic per non-empty bin per item
+//                instead of seven per triangle)
+//   k_sah_multi  one wave per (large node, axis): the same evaluation over the global bins
+//                (evaluation = suffix boxes, prefix boxes and counts by wave scans, cost of every split
+//                in its own lane, minimum with the later split winning a tie)
 //   k_choose     one lane per node: best axis, child records
 //   scan + k_scatter   stable partition of every splitting node's segment at once
 // then sizes bottom-up, DFS indices top-down, and one pass that writes nodes, order and matrices.
@@ -51,6 +57,7 @@ struct Slot {
   uint32_t n;
   float start[3], inv[3];
   uint32_t axis_mask; // bit a: axis a is wide enough to be split (bvh.cpp:169)
+  uint32_t multi;     // index of the node's global bins when it spans several work items, else kNone
 };
 
 struct AxisBest {
@@ -228,7 +235,9 @@ __global__ void k_level_flags(const BNode* __restrict__ nodes, uint32_t ls, uint
 }
 
 __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, const uint32_t* __restrict__ flag,
-                             const uint32_t* __restrict__ slot_of, uint32_t num_bins, Slot* __restrict__ slots) {
+                             const uint32_t* __restrict__ slot_of, uint32_t num_bins, uint32_t chunk,
+                             Slot* __restrict__ slots, uint32_t* __restrict__ items,
+                             uint32_t* __restrict__ multi_count, uint32_t* __restrict__ multi_list) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   BNode& nd = nodes[ls + i];
@@ -249,7 +258,10 @@ __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
     sl.inv[a] = 1.0f / step;                            // bvh.cpp:153
     if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) sl.axis_mask |= 1u << a; // bvh.cpp:169
   }
+  sl.multi = sl.n > chunk ? atomicAdd(multi_count, 1u) : kNone; // which bins it gets does not matter
+  if (sl.multi != kNone) multi_list[sl.multi] = s;
   slots[s] = sl;
+  items[s] = (sl.n + chunk - 1) / chunk;
 }
 
 // bvh.cpp:161-162: min(uvec3((center - bin_start) * inv_bin_step), num_splits)
@@ -259,86 +271,245 @@ __device__ __forceinline__ uint32_t bin_index(float c, float start, float inv, u
   return b < num_splits ? b : num_splits;
 }
 
-__global__ void k_bin(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
-                      const BNode* __restrict__ nodes, uint32_t ls, const Slot* __restrict__ slots,
-                      const float4* __restrict__ tbox, uint32_t num_bins, Bin* __restrict__ bins) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t nd = node_of[k];
-  if (nd < ls) return;
-  const uint32_t s = nodes[nd].slot;
-  if (s == kNone) return;
-  const Slot& sl = slots[s];
-  const uint32_t t = order[k];
-  const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
-  const float tp[3] = { top.x, top.y, top.z }, bt[3] = { bot.x, bot.y, bot.z };
-  uint32_t et[3], eb[3];
-  for (int a = 0; a < 3; a++) {
-    et[a] = enc(tp[a]);
-    eb[a] = ~enc(bt[a]);
+// ---- split evaluation by one wave (bvh.cpp:54-105) ---------------------------------------------------
+struct CountBox {
+  uint32_t n;
+  Box3 box;
+};
+__device__ __forceinline__ CountBox empty_count_box() {
+  CountBox c;
+  c.n = 0;
+  for (int i = 0; i < 3; i++) {
+    c.box.top[i] = -kFltMax;
+    c.box.bot[i] = kFltMax;
   }
-  for (int a = 0; a < 3; a++) {
-    if (!(sl.axis_mask >> a & 1u)) continue;
-    const float c = (tp[a] + bt[a]) * 0.5f; // AABB::get_center
-    const uint32_t b = bin_index(c, sl.start[a], sl.inv[a], num_bins - 1);
-    Bin* bin = bins + (static_cast<size_t>(s) * 3 + a) * num_bins + b;
-    atomicAdd(&bin->count, 1u);
-    for (int j = 0; j < 3; j++) {
-      raise(&bin->mx[j], et[j]);
-      raise(&bin->mn[j], eb[j]);
+  return c;
+}
+__device__ __forceinline__ void combine(CountBox& a, const CountBox& b) {
+  a.n += b.n;
+  grow(a.box, b.box);
+}
+__device__ __forceinline__ CountBox shuffle_from(const CountBox& v, int src_lane) {
+  CountBox o;
+  o.n = __shfl(v.n, src_lane, 64);
+  for (int i = 0; i < 3; i++) {
+    o.box.top[i] = __shfl(v.box.top[i], src_lane, 64);
+    o.box.bot[i] = __shfl(v.box.bot[i], src_lane, 64);
+  }
+  return o;
+}
+
+// `load(b)` returns bin b (b < num_bins).  rb: 6 * num_bins floats of LDS, rb[j * num_bins + b].
+// All 64 lanes of the wave call this; lane 0 writes *out.
+template <class Load>
+__device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis, Load load, float* rb, AxisBest* out) {
+  const int lane = static_cast<int>(threadIdx.x & 63u);
+  const uint32_t chunks = (num_bins + 63) / 64;
+  // right_bounds[b] = box of bins b .. num_bins-1
+  CountBox carry = empty_count_box();
+  for (uint32_t c = chunks; c-- > 0;) {
+    const uint32_t b = c * 64 + lane;
+    CountBox v = b < num_bins ? load(b) : empty_count_box();
+    for (int d = 1; d < 64; d <<= 1) {
+      const CountBox o = shuffle_from(v, lane + d < 64 ? lane + d : lane);
+      if (lane + d < 64) combine(v, o);
     }
+    combine(v, carry);
+    if (b < num_bins)
+      for (int j = 0; j < 3; j++) {
+        rb[j * num_bins + b] = v.box.top[j];
+        rb[(3 + j) * num_bins + b] = v.box.bot[j];
+      }
+    carry = shuffle_from(v, 0);
+  }
+  __syncthreads(); // the block is this one wave: its LDS writes above are visible to its reads below
+  // left_bounds[s] = box of bins 0 .. s; every split s < num_bins - 1 in its own lane
+  bool has = false;
+  float best_cost = kFltMax;
+  uint32_t best_index = 0, best_left_n = 0;
+  Box3 best_left, best_right;
+  for (int i = 0; i < 3; i++) best_left.top[i] = best_left.bot[i] = best_right.top[i] = best_right.bot[i] = 0.0f;
+  carry = empty_count_box();
+  for (uint32_t c = 0; c < chunks; c++) {
+    const uint32_t s = c * 64 + lane;
+    CountBox v = s < num_bins ? load(s) : empty_count_box();
+    for (int d = 1; d < 64; d <<= 1) {
+      const CountBox o = shuffle_from(v, lane >= d ? lane - d : lane);
+      if (lane >= d) combine(v, o);
+    }
+    // carry first, as the sequential loop grows left to right (only the sign of a zero could differ)
+    CountBox left = carry;
+    combine(left, v);
+    if (s + 1 < num_bins) {
+      const uint32_t left_n = left.n, right_n = n - left_n;
+      if (left_n > 2 && right_n > 2) {
+        Box3 right;
+        for (int j = 0; j < 3; j++) {
+          right.top[j] = rb[j * num_bins + s];
+          right.bot[j] = rb[(3 + j) * num_bins + s];
+        }
+        const float total = cost(left.box.top, left.box.bot, left_n) + cost(right.top, right.bot, right_n);
+        if (total <= kFltMax && !(best_cost < total)) {
+          has = true;
+          best_cost = total;
+          best_index = s;
+          best_left_n = left_n;
+          best_left = left.box;
+          best_right = right;
+        }
+      }
+    }
+    carry = shuffle_from(left, 63);
+  }
+  // smallest cost, the later split on a tie (SplitParams::min, bvh.hpp)
+  float key = has ? best_cost : __builtin_inff();
+  uint32_t idx = best_index;
+  for (int d = 32; d > 0; d >>= 1) {
+    const float ok = __shfl_xor(key, d, 64);
+    const uint32_t oi = __shfl_xor(idx, d, 64);
+    if (ok < key || (ok == key && oi > idx)) {
+      key = ok;
+      idx = oi;
+    }
+  }
+  const bool any = key != __builtin_inff();
+  if (any && has && best_index == idx && best_cost == key) {
+    AxisBest r;
+    r.cost = best_cost;
+    r.index = best_index;
+    r.left_n = best_left_n;
+    r.axis = axis;
+    for (int i = 0; i < 3; i++) {
+      r.ltop[i] = best_left.top[i];
+      r.lbot[i] = best_left.bot[i];
+      r.rtop[i] = best_right.top[i];
+      r.rbot[i] = best_right.bot[i];
+    }
+    *out = r;
+  }
+  if (!any && lane == 0) {
+    AxisBest r;
+    r.cost = kFltMax;
+    r.index = r.left_n = 0;
+    r.axis = -1;
+    for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
+    *out = r;
   }
 }
 
-// bvh.cpp:54-105 for one (node, axis)
-__global__ void k_sah(const Slot* __restrict__ slots, uint32_t n_slots, uint32_t num_bins,
-                      const Bin* __restrict__ bins, Box3* __restrict__ right_bounds, AxisBest* __restrict__ best_out) {
-  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= n_slots * 3) return;
-  const uint32_t s = id / 3, axis = id % 3;
-  const Slot& sl = slots[s];
-  AxisBest best;
-  best.cost = kFltMax;
-  best.index = 0;
-  best.left_n = 0;
-  best.axis = -1;
-  for (int i = 0; i < 3; i++) best.ltop[i] = best.lbot[i] = best.rtop[i] = best.rbot[i] = 0.0f;
-  if (sl.axis_mask >> axis & 1u) {
-    const Bin* b = bins + static_cast<size_t>(id) * num_bins;
-    Box3* rb = right_bounds + static_cast<size_t>(id) * num_bins;
-    Box3 acc = load_bin(b[num_bins - 1]);
-    rb[num_bins - 1] = acc;
-    for (int32_t i = static_cast<int32_t>(num_bins) - 2; i >= 0; i--) {
-      grow(acc, load_bin(b[i]));
-      rb[i] = acc;
+// One wave per work item.  Dynamic LDS: 7 * num_bins words of bins (count, 3 enc(max), 3 ~enc(min),
+// each its own array) + 6 * num_bins floats of suffix boxes.
+__global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ order, const BNode* __restrict__ nodes,
+                                                const Slot* __restrict__ slots, uint32_t n_slots,
+                                                const uint32_t* __restrict__ item_base,
+                                                const uint32_t* __restrict__ n_items_ptr, uint32_t chunk,
+                                                const float4* __restrict__ tbox, uint32_t num_bins,
+                                                Bin* __restrict__ multi_bins, AxisBest* __restrict__ axis_best) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t item = blockIdx.x;
+  if (item >= *n_items_ptr) return;
+  const uint32_t lane = threadIdx.x;
+  // the slot whose items include `item`: last s with item_base[s] <= item (every slot has >= 1 item)
+  uint32_t lo = 0, hi = n_slots - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (item_base[mid] <= item) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t s = lo;
+  const Slot sl = slots[s];
+  const BNode& nd = nodes[sl.node];
+  const uint32_t first = nd.begin + (item - item_base[s]) * chunk;
+  const uint32_t last = first + chunk < nd.end ? first + chunk : nd.end;
+  uint32_t* cnt = lds;
+  uint32_t* mx = lds + num_bins;     // [3][num_bins]
+  uint32_t* mn = lds + 4 * num_bins; // [3][num_bins]
+  float* rb = reinterpret_cast<float*>(lds + 7 * num_bins);
+  for (int a = 0; a < 3; a++) {
+    if (!(sl.axis_mask >> a & 1u)) {
+      if (sl.multi == kNone && lane == 0) {
+        AxisBest r;
+        r.cost = kFltMax;
+        r.index = r.left_n = 0;
+        r.axis = -1;
+        for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
+        axis_best[s * 3 + a] = r;
+      }
+      continue;
     }
-    Box3 left = load_bin(b[0]);
-    uint32_t left_n = b[0].count;
-    const uint32_t num_splits = num_bins - 1;
-    for (uint32_t split = 0; split < num_splits; split++) {
-      const uint32_t right_n = sl.n - left_n;
-      if (left_n > 2 && right_n > 2) {
-        // the reference pairs left_bounds[s] with right_bounds[s] (bvh.cpp:77-81)
-        const Box3 right = rb[split];
-        const float total = cost(left.top, left.bot, left_n) + cost(right.top, right.bot, right_n);
-        if (!(best.cost < total)) {
-          best.cost = total;
-          best.index = split;
-          best.left_n = left_n;
-          best.axis = static_cast<int32_t>(axis);
-          for (int i = 0; i < 3; i++) {
-            best.ltop[i] = left.top[i];
-            best.lbot[i] = left.bot[i];
-            best.rtop[i] = right.top[i];
-            best.rbot[i] = right.bot[i];
-          }
+    for (uint32_t b = lane; b < 7 * num_bins; b += 64) lds[b] = 0;
+    __syncthreads();
+    for (uint32_t k = first + lane; k < last; k += 64) {
+      const uint32_t t = order[k];
+      const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
+      const float tp = a == 0 ? top.x : (a == 1 ? top.y : top.z);
+      const float bt = a == 0 ? bot.x : (a == 1 ? bot.y : bot.z);
+      const uint32_t b = bin_index((tp + bt) * 0.5f, sl.start[a], sl.inv[a], num_bins - 1); // AABB::get_center
+      atomicAdd(&cnt[b], 1u);
+      atomicMax(&mx[b], enc(top.x));
+      atomicMax(&mx[num_bins + b], enc(top.y));
+      atomicMax(&mx[2 * num_bins + b], enc(top.z));
+      atomicMax(&mn[b], ~enc(bot.x));
+      atomicMax(&mn[num_bins + b], ~enc(bot.y));
+      atomicMax(&mn[2 * num_bins + b], ~enc(bot.z));
+    }
+    __syncthreads();
+    if (sl.multi == kNone) {
+      auto load = [&](uint32_t b) {
+        CountBox c;
+        c.n = cnt[b];
+        for (int j = 0; j < 3; j++) {
+          c.box.top[j] = dec_max(mx[j * num_bins + b]);
+          c.box.bot[j] = dec_min(mn[j * num_bins + b]);
+        }
+        return c;
+      };
+      wave_sah(num_bins, sl.n, a, load, rb, &axis_best[s * 3 + a]);
+    } else {
+      Bin* gb = multi_bins + (static_cast<size_t>(sl.multi) * 3 + a) * num_bins;
+      for (uint32_t b = lane; b < num_bins; b += 64) {
+        const uint32_t c = cnt[b];
+        if (c == 0) continue;
+        atomicAdd(&gb[b].count, c);
+        for (int j = 0; j < 3; j++) {
+          raise(&gb[b].mx[j], mx[j * num_bins + b]);
+          raise(&gb[b].mn[j], mn[j * num_bins + b]);
         }
       }
-      grow(left, load_bin(b[split + 1]));
-      left_n += b[split + 1].count;
     }
+    __syncthreads();
   }
-  best_out[id] = best;
+}
+
+// One wave per (node with global bins, axis).  Dynamic LDS: 6 * num_bins floats.
+__global__ void __launch_bounds__(64) k_sah_multi(const Slot* __restrict__ slots,
+                                                  const uint32_t* __restrict__ multi_list,
+                                                  const uint32_t* __restrict__ multi_count, uint32_t num_bins,
+                                                  const Bin* __restrict__ multi_bins, AxisBest* __restrict__ axis_best) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t m = blockIdx.x / 3;
+  const int a = static_cast<int>(blockIdx.x % 3);
+  if (m >= *multi_count) return;
+  const uint32_t s = multi_list[m];
+  const Slot sl = slots[s];
+  if (!(sl.axis_mask >> a & 1u)) {
+    if (threadIdx.x == 0) {
+      AxisBest r;
+      r.cost = kFltMax;
+      r.index = r.left_n = 0;
+      r.axis = -1;
+      for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
+      axis_best[s * 3 + a] = r;
+    }
+    return;
+  }
+  const Bin* gb = multi_bins + (static_cast<size_t>(sl.multi) * 3 + a) * num_bins;
+  auto load = [&](uint32_t b) {
+    CountBox c;
+    c.n = gb[b].count;
+    c.box = load_bin(gb[b]);
+    return c;
+  };
+  wave_sah(num_bins, sl.n, a, load, reinterpret_cast<float*>(lds), &axis_best[s * 3 + a]);
 }
 
 // bvh.cpp:141-142, 184-190: the best of the node's own cost and the three axes, later wins a tie
@@ -607,8 +778,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   auto grid = [](uint64_t items) { return static_cast<uint32_t>((items + kB - 1) / kB); };
   const uint64_t cap = max_nodes(n);
 
-  DeviceBuffer tbox, order[2], node_of[2], nodes, misc, flags, ranks, slots, bins, rbounds, axis_best, choice,
-    gl, gls, flat_index, tri_offset;
+  DeviceBuffer tbox, order[2], node_of[2], nodes, misc, flags, ranks, slots, items, item_base, multi_list, bins,
+    axis_best, choice, gl, gls, flat_index, tri_offset;
   BVHB_TRY(tbox.reserve(static_cast<size_t>(n) * 32));
   for (int i = 0; i < 2; i++) {
     BVHB_TRY(order[i].reserve(static_cast<size_t>(n) * 4));
@@ -620,6 +791,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(gls.reserve(static_cast<size_t>(n) * 4));
   uint32_t* d_root = misc.as<uint32_t>();      // 6 words
   uint32_t* d_total = misc.as<uint32_t>() + 8; // scan total
+  uint32_t* d_multi_count = misc.as<uint32_t>() + 9;
   uint32_t* h_total = nullptr;
   BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64));
   struct Pinned {
@@ -672,21 +844,34 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     if (rc) return rc;
     if (n_slots == 0) break;
 
-    const size_t n_bins = static_cast<size_t>(n_slots) * 3 * num_bins;
+    // work items: `chunk` consecutive positions of one node; a node of more than one item has global bins
+    const uint32_t chunk = 16 * num_bins > 1024 ? 16 * num_bins : 1024;
+    const uint32_t max_multi = n / chunk < n_slots ? n / chunk : n_slots; // nodes with more than `chunk` triangles
+    const uint32_t max_items = n / chunk + n_slots;
+    const size_t n_bins = static_cast<size_t>(max_multi) * 3 * num_bins;
     BVHB_TRY(slots.reserve(static_cast<size_t>(n_slots) * sizeof(Slot)));
-    BVHB_TRY(bins.reserve(n_bins * sizeof(Bin)));
-    BVHB_TRY(rbounds.reserve(n_bins * sizeof(Box3)));
+    BVHB_TRY(items.reserve(static_cast<size_t>(n_slots) * 4));
+    BVHB_TRY(item_base.reserve(static_cast<size_t>(n_slots) * 4));
+    BVHB_TRY(multi_list.reserve(static_cast<size_t>(max_multi + 1) * 4));
+    BVHB_TRY(bins.reserve(n_bins * sizeof(Bin) + 16));
     BVHB_TRY(axis_best.reserve(static_cast<size_t>(n_slots) * 3 * sizeof(AxisBest)));
     BVHB_TRY(choice.reserve(static_cast<size_t>(n_slots) * sizeof(Choice)));
-    peak_bins = n_bins * (sizeof(Bin) + sizeof(Box3)) > peak_bins ? n_bins * (sizeof(Bin) + sizeof(Box3)) : peak_bins;
+    peak_bins = n_bins * sizeof(Bin) > peak_bins ? n_bins * sizeof(Bin) : peak_bins;
+    BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 4, stream));
     k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
-                                            num_bins, slots.as<Slot>());
-    BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
-    k_bin<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls,
-                                     slots.as<Slot>(), tbox.as<float4>(), num_bins, bins.as<Bin>());
-    k_sah<<<grid(static_cast<uint64_t>(n_slots) * 3), kB, 0, stream>>>(slots.as<Slot>(), n_slots, num_bins,
-                                                                      bins.as<Bin>(), rbounds.as<Box3>(),
-                                                                      axis_best.as<AxisBest>());
+                                            num_bins, chunk, slots.as<Slot>(), items.as<uint32_t>(), d_multi_count,
+                                            multi_list.as<uint32_t>());
+    rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>()); // total -> *d_total
+    if (rc) return rc;
+    if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
+    k_bin_sah<<<max_items, 64, 13 * num_bins * 4, stream>>>(order[cur].as<uint32_t>(), nodes.as<BNode>(),
+                                                           slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total,
+                                                           chunk, tbox.as<float4>(), num_bins, bins.as<Bin>(),
+                                                           axis_best.as<AxisBest>());
+    if (max_multi)
+      k_sah_multi<<<max_multi * 3, 64, 6 * num_bins * 4, stream>>>(slots.as<Slot>(), multi_list.as<uint32_t>(),
+                                                                  d_multi_count, num_bins, bins.as<Bin>(),
+                                                                  axis_best.as<AxisBest>());
     // flags / ranks are reused per slot from here on (n_slots <= m)
     k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
                                               choice.as<Choice>(), flags.as<uint32_t>());
