@@ -28,8 +28,10 @@ EXPORTS = [
     "nova_hip_image_write", "nova_hip_image_copy", "nova_hip_image_fill",
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
     "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
-    "nova_hip_reset_counters",
+    "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
 ]
+# error codes (include/nova_hip.h)
+E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE = -1, -2, -3, -4, -5
 
 
 class NovaHipError(RuntimeError):

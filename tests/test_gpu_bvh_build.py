@@ -1,0 +1,138 @@
+"""GPU (-m gpu): nova_hip_build_bvh (BVH::build + the TriangleData loop on the device, SURVEY.md §8f
+rank 1) through the C ABI against the CPU builder (nova_amd/csrc/host/scene_build.cpp, the restatement
+of src/bvh/bvh.cpp and intersectable_manager.cpp:129-145 that the reference's own AABB / Triangle known
+answers pin, tests/test_reference_kats.py).  Bar: the same tree — every FlatBVHNode equal (the sign of
+a zero box coordinate aside, which compares equal), the same triangle order, Woop matrices bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from nova_amd import capi, scene as S
+from tests.helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    capi.init(0)
+    yield
+
+
+def assert_same_tree(verts):
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+    host = S.build_scene(verts)
+    bvh, tris, order, stats = capi.build_bvh(verts)
+    assert len(bvh) == len(host.bvh)
+    for f in ("top_offset_left", "bottom_num_right"):
+        np.testing.assert_array_equal(bvh[f], host.bvh[f])
+    np.testing.assert_array_equal(order, host.tri_order)
+    want = host.triangles.view(np.float32).reshape(-1, 12)
+    both_nan = np.isnan(tris) & np.isnan(want)  # a zero-area triangle has no inverse; NaN payloads are the CPU's
+    assert np.array_equal(tris.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
+    assert stats["levels"] == host.max_depth
+    return host, stats
+
+
+def test_cornell_box():
+    z = golden("cornell_box.npz")
+    host, _ = assert_same_tree(z["verts"])
+    assert len(host.bvh) > 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 9, 10, 17, 64, 65, 1000])
+def test_small_inputs_and_the_leaf_threshold(n):
+    assert_same_tree(S.soup(n, seed=n, edge=0.3))
+
+
+@pytest.mark.parametrize("name", ["soup50k", "knot96", "room", "thin_long", "clustered"])
+def test_scenes(name):
+    rng = np.random.default_rng(9)
+    if name == "soup50k":
+        v = S.soup(50000, seed=4, edge=0.05)
+    elif name == "knot96":
+        v = S.knot_mesh(96, 96)
+    elif name == "room":
+        v = S.room_scene(n_objects=20, res=9)[0]
+    elif name == "thin_long":  # long needles: centres far from most of the box, deep unbalanced trees
+        c = rng.uniform(-1, 1, (20000, 1, 3)).astype(np.float32)
+        d = rng.normal(size=(20000, 1, 3)).astype(np.float32)
+        t = np.array([0.0, 0.5, 1.0], np.float32).reshape(1, 3, 1) * np.float32(0.6)
+        v = (c + d * t + rng.normal(size=(20000, 3, 3)).astype(np.float32) * np.float32(0.002)).reshape(-1, 9)
+    else:  # a few dense clusters and a sparse background: very uneven bins
+        centres = rng.uniform(-1, 1, (6, 3))
+        pts = np.concatenate([centres[i % 6] + rng.normal(size=(5000, 3)) * 0.01 * (1 + i) for i in range(6)] +
+                             [rng.uniform(-1, 1, (3000, 3))]).astype(np.float32)
+        v = (pts[:, None, :] + rng.normal(size=(len(pts), 3, 3)).astype(np.float32) * 0.004).reshape(-1, 9)
+    assert_same_tree(v)
+
+
+def test_degenerate_inputs():
+    rng = np.random.default_rng(3)
+    one = S.soup(1, seed=1, edge=0.3)
+    # 40 copies of one triangle: every centre in one bin, no split is valid, one big leaf
+    host, _ = assert_same_tree(np.repeat(one, 40, axis=0))
+    assert len(host.bvh) == 1
+    # all triangles in the plane z = 0: the z axis is not split (bvh.cpp:169)
+    flat = S.soup(3000, seed=5, edge=0.05) * np.tile(np.array([1, 1, 0], np.float32), 3)
+    assert_same_tree(flat)
+    # exact zeros and negative zeros among the coordinates, zero-area triangles
+    v = S.soup(2000, seed=6, edge=0.2)
+    v[rng.random(v.shape) < 0.05] = 0.0
+    v[rng.random(v.shape) < 0.02] = -0.0
+    v[::97, 3:6] = v[::97, 0:3]
+    assert_same_tree(v)
+    # far from the origin and tiny: steps near the float spacing
+    assert_same_tree(S.soup(5000, seed=7, edge=0.001) * np.float32(1e-3) + np.float32(1000.0))
+    # a regular grid: many triangles exactly on bin boundaries, many equal costs (later split wins)
+    g = np.stack(np.meshgrid(np.arange(64, dtype=np.float32), np.arange(64, dtype=np.float32)), -1).reshape(-1, 2)
+    quad = np.zeros((len(g), 9), np.float32)
+    quad[:, 0:2] = g
+    quad[:, 3:5] = g + np.array([1, 0], np.float32)
+    quad[:, 6:8] = g + np.array([0, 1], np.float32)
+    quad[:, 2] = quad[:, 5] = quad[:, 8] = (g[:, 0] % 2) * 0.5
+    assert_same_tree(quad / np.float32(64.0))
+
+
+def test_full_size_frame_scene():
+    """BASELINE config 2's stand-in (871 200 triangles): the same tree, and faster than the CPU."""
+    host, stats = assert_same_tree(S.knot_mesh(660, 660))
+    assert len(host.bvh) > 250_000
+    assert stats["device_ms"] < 100.0
+
+
+def test_errors():
+    lib = capi.load()
+    v = S.soup(10, seed=1, edge=0.3)
+    cap = int(lib.nova_hip_bvh_max_nodes(10))
+    bvh = np.zeros(cap, S.BVH_NODE)
+    tris = np.zeros((10, 12), np.float32)
+    order = np.zeros(10, np.uint32)
+    n_nodes = ctypes.c_uint64(0)
+    args = (v.ctypes.data, 10, bvh.ctypes.data, cap, ctypes.byref(n_nodes), tris.ctypes.data, order.ctypes.data, None)
+    assert lib.nova_hip_build_bvh(*args) == 0 and n_nodes.value >= 1
+    assert lib.nova_hip_build_bvh(None, *args[1:]) == capi.E_INVALID_ARGUMENT
+    assert lib.nova_hip_build_bvh(args[0], 0, *args[2:]) == capi.E_INVALID_ARGUMENT
+    assert lib.nova_hip_build_bvh(*args[:3], cap - 1, *args[4:]) == capi.E_INVALID_ARGUMENT
+    assert lib.nova_hip_build_bvh(args[0], (1 << 24) + 1, *args[2:]) == capi.E_TOO_LARGE
+    assert lib.nova_hip_bvh_max_nodes(1) == 1 and lib.nova_hip_bvh_max_nodes(9) == 5
+
+
+def test_a_scene_built_on_the_device_renders_the_same_frame():
+    from nova_amd.raytracer import Raytracer
+    verts = S.soup(20000, seed=8, edge=0.08)
+    host = S.build_scene(verts)
+    bvh, tris, order, _ = capi.build_bvh(verts)
+    dev = S.Scene(bvh, tris.view(S.TRIANGLE_DATA).reshape(-1), host.meta, host.lights, order, host.verts,
+                  host.max_depth, host.materials, host.sky)
+    w, h = 96, 64
+    p = S.make_scene_params(S.Camera(width=w, height=h, position=[0, 0, 3.5], target=[0, 0, 0], up=[0, 1, 0],
+                                     fovy=40.0))
+    frames = []
+    for sc in (host, dev):
+        rt = Raytracer(0)
+        rt.set_scene(sc, p, w, h)
+        rt.kernel_raytrace(3)
+        frames.append(rt.temp_color_img1.read())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
