@@ -58,6 +58,7 @@ struct Slot {
   float start[3], inv[3];
   uint32_t axis_mask; // bit a: axis a is wide enough to be split (bvh.cpp:169)
   uint32_t multi;     // index of the node's global bins when it spans several work items, else kNone
+  uint32_t part_base; // such a node's items write their bins to partial slabs part_base, part_base + 1, ...
 };
 
 struct AxisBest {
@@ -237,7 +238,8 @@ __global__ void k_level_flags(const BNode* __restrict__ nodes, uint32_t ls, uint
 __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, const uint32_t* __restrict__ flag,
                              const uint32_t* __restrict__ slot_of, uint32_t num_bins, uint32_t chunk,
                              Slot* __restrict__ slots, uint32_t* __restrict__ items,
-                             uint32_t* __restrict__ multi_count, uint32_t* __restrict__ multi_list) {
+                             uint32_t* __restrict__ multi_count, uint32_t* __restrict__ multi_list,
+                             uint32_t* __restrict__ multi_items) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   BNode& nd = nodes[ls + i];
@@ -259,9 +261,14 @@ __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
     if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) sl.axis_mask |= 1u << a; // bvh.cpp:169
   }
   sl.multi = sl.n > chunk ? atomicAdd(multi_count, 1u) : kNone; // which bins it gets does not matter
-  if (sl.multi != kNone) multi_list[sl.multi] = s;
+  const uint32_t n_items = (sl.n + chunk - 1) / chunk;
+  sl.part_base = 0;
+  if (sl.multi != kNone) {
+    multi_list[sl.multi] = s;
+    sl.part_base = atomicAdd(multi_items, n_items);
+  }
   slots[s] = sl;
-  items[s] = (sl.n + chunk - 1) / chunk;
+  items[s] = n_items;
 }
 
 // bvh.cpp:161-162: min(uvec3((center - bin_start) * inv_bin_step), num_splits)
@@ -397,14 +404,17 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
   }
 }
 
-// One wave per work item.  Dynamic LDS: 7 * num_bins words of bins (count, 3 enc(max), 3 ~enc(min),
-// each its own array) + 6 * num_bins floats of suffix boxes.
+// One wave per work item.  Dynamic LDS: per axis held, 7 * num_bins words of bins (count, 3 enc(max),
+// 3 ~enc(min), each its own array), then 6 * num_bins floats of suffix boxes.  FUSED: the three axes are
+// binned in one pass over the triangles (21 * num_bins words of bins); otherwise one pass per axis.
+template <bool FUSED>
 __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ order, const BNode* __restrict__ nodes,
                                                 const Slot* __restrict__ slots, uint32_t n_slots,
                                                 const uint32_t* __restrict__ item_base,
                                                 const uint32_t* __restrict__ n_items_ptr, uint32_t chunk,
                                                 const float4* __restrict__ tbox, uint32_t num_bins,
-                                                Bin* __restrict__ multi_bins, AxisBest* __restrict__ axis_best) {
+                                                uint32_t* __restrict__ partials, uint32_t* __restrict__ part_owner,
+                                                uint32_t* __restrict__ pbins, AxisBest* __restrict__ axis_best) {
   extern __shared__ uint32_t lds[];
   const uint32_t item = blockIdx.x;
   if (item >= *n_items_ptr) return;
@@ -420,64 +430,129 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
   const BNode& nd = nodes[sl.node];
   const uint32_t first = nd.begin + (item - item_base[s]) * chunk;
   const uint32_t last = first + chunk < nd.end ? first + chunk : nd.end;
-  uint32_t* cnt = lds;
-  uint32_t* mx = lds + num_bins;     // [3][num_bins]
-  uint32_t* mn = lds + 4 * num_bins; // [3][num_bins]
-  float* rb = reinterpret_cast<float*>(lds + 7 * num_bins);
-  for (int a = 0; a < 3; a++) {
-    if (!(sl.axis_mask >> a & 1u)) {
-      if (sl.multi == kNone && lane == 0) {
-        AxisBest r;
-        r.cost = kFltMax;
-        r.index = r.left_n = 0;
-        r.axis = -1;
-        for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
-        axis_best[s * 3 + a] = r;
+  if (sl.multi != kNone && lane == 0) part_owner[sl.part_base + (item - item_base[s])] = sl.multi;
+  constexpr int kHeld = FUSED ? 3 : 1; // axes whose bins are in LDS at once
+  float* rb = reinterpret_cast<float*>(lds + kHeld * 7 * num_bins);
+  const uint32_t num_splits = num_bins - 1;
+
+  auto add = [&](uint32_t* bins, int a, const float4& top, const float4& bot) -> uint32_t {
+    const float tp = a == 0 ? top.x : (a == 1 ? top.y : top.z);
+    const float bt = a == 0 ? bot.x : (a == 1 ? bot.y : bot.z);
+    const uint32_t b = bin_index((tp + bt) * 0.5f, sl.start[a], sl.inv[a], num_splits); // AABB::get_center
+    atomicAdd(&bins[b], 1u);
+    atomicMax(&bins[num_bins + b], enc(top.x));
+    atomicMax(&bins[2 * num_bins + b], enc(top.y));
+    atomicMax(&bins[3 * num_bins + b], enc(top.z));
+    atomicMax(&bins[4 * num_bins + b], ~enc(bot.x));
+    atomicMax(&bins[5 * num_bins + b], ~enc(bot.y));
+    atomicMax(&bins[6 * num_bins + b], ~enc(bot.z));
+    return b;
+  };
+
+  for (int pass = 0; pass < (FUSED ? 1 : 3); pass++) {
+    const uint32_t pass_mask = FUSED ? sl.axis_mask : (sl.axis_mask & (1u << pass));
+    if (pass_mask) {
+      for (uint32_t b = lane; b < kHeld * 7 * num_bins; b += 64) lds[b] = 0;
+      __syncthreads();
+      // four positions per lane in flight: the order -> box gathers are what this loop waits for
+      for (uint32_t k0 = first + lane; k0 < last; k0 += 256) {
+        uint32_t t[4];
+        float4 top[4], bot[4];
+        for (int j = 0; j < 4; j++) {
+          const uint32_t k = k0 + 64 * j;
+          t[j] = k < last ? order[k] : kNone;
+        }
+        for (int j = 0; j < 4; j++)
+          if (t[j] != kNone) {
+            top[j] = tbox[2ull * t[j]];
+            bot[j] = tbox[2ull * t[j] + 1];
+          }
+        for (int j = 0; j < 4; j++)
+          if (t[j] != kNone) {
+            // the three bin indices of a position, 10 bits each, for the partition (k_goes_left)
+            const uint32_t k = k0 + 64 * j;
+            if (FUSED) {
+              uint32_t packed = 0;
+              for (int a = 0; a < 3; a++)
+                if (pass_mask >> a & 1u) packed |= add(lds + a * 7 * num_bins, a, top[j], bot[j]) << (10 * a);
+              pbins[k] = packed;
+            } else {
+              const uint32_t b = add(lds, pass, top[j], bot[j]) << (10 * pass);
+              pbins[k] = (sl.axis_mask & ((1u << pass) - 1u)) ? (pbins[k] | b) : b; // first pass taken writes
+            }
+          }
       }
-      continue;
+      __syncthreads();
     }
-    for (uint32_t b = lane; b < 7 * num_bins; b += 64) lds[b] = 0;
-    __syncthreads();
-    for (uint32_t k = first + lane; k < last; k += 64) {
-      const uint32_t t = order[k];
-      const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
-      const float tp = a == 0 ? top.x : (a == 1 ? top.y : top.z);
-      const float bt = a == 0 ? bot.x : (a == 1 ? bot.y : bot.z);
-      const uint32_t b = bin_index((tp + bt) * 0.5f, sl.start[a], sl.inv[a], num_bins - 1); // AABB::get_center
-      atomicAdd(&cnt[b], 1u);
-      atomicMax(&mx[b], enc(top.x));
-      atomicMax(&mx[num_bins + b], enc(top.y));
-      atomicMax(&mx[2 * num_bins + b], enc(top.z));
-      atomicMax(&mn[b], ~enc(bot.x));
-      atomicMax(&mn[num_bins + b], ~enc(bot.y));
-      atomicMax(&mn[2 * num_bins + b], ~enc(bot.z));
-    }
-    __syncthreads();
-    if (sl.multi == kNone) {
-      auto load = [&](uint32_t b) {
-        CountBox c;
-        c.n = cnt[b];
-        for (int j = 0; j < 3; j++) {
-          c.box.top[j] = dec_max(mx[j * num_bins + b]);
-          c.box.bot[j] = dec_min(mn[j * num_bins + b]);
+    for (int a = FUSED ? 0 : pass; a < (FUSED ? 3 : pass + 1); a++) {
+      if (!(sl.axis_mask >> a & 1u)) {
+        if (sl.multi == kNone && lane == 0) {
+          AxisBest r;
+          r.cost = kFltMax;
+          r.index = r.left_n = 0;
+          r.axis = -1;
+          for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
+          axis_best[s * 3 + a] = r;
         }
-        return c;
-      };
-      wave_sah(num_bins, sl.n, a, load, rb, &axis_best[s * 3 + a]);
-    } else {
-      Bin* gb = multi_bins + (static_cast<size_t>(sl.multi) * 3 + a) * num_bins;
-      for (uint32_t b = lane; b < num_bins; b += 64) {
-        const uint32_t c = cnt[b];
-        if (c == 0) continue;
-        atomicAdd(&gb[b].count, c);
-        for (int j = 0; j < 3; j++) {
-          raise(&gb[b].mx[j], mx[j * num_bins + b]);
-          raise(&gb[b].mn[j], mn[j * num_bins + b]);
-        }
+        continue;
+      }
+      const uint32_t* bins = lds + (FUSED ? a : 0) * 7 * num_bins;
+      if (sl.multi == kNone) {
+        auto load = [&](uint32_t b) {
+          CountBox c;
+          c.n = bins[b];
+          for (int j = 0; j < 3; j++) {
+            c.box.top[j] = dec_max(bins[(1 + j) * num_bins + b]);
+            c.box.bot[j] = dec_min(bins[(4 + j) * num_bins + b]);
+          }
+          return c;
+        };
+        wave_sah(num_bins, sl.n, a, load, rb, &axis_best[s * 3 + a]);
+        __syncthreads(); // rb is reused by the next axis
+      } else {
+        // this item's bins go to its slab; k_reduce_partials adds the slabs of a node up
+        const uint32_t pi = sl.part_base + (item - item_base[s]);
+        uint32_t* dst = partials + static_cast<size_t>(pi) * 21 * num_bins + static_cast<size_t>(a) * 7 * num_bins;
+        for (uint32_t b = lane; b < 7 * num_bins; b += 64) dst[b] = bins[b];
       }
     }
     __syncthreads();
   }
+}
+
+// Sum of the slabs of every large node into its global bins.  x: the 21 * num_bins words of a slab
+// (axis, field, bin); y: groups of kReduceGroup consecutive slabs, one atomic per word, group and node.
+constexpr uint32_t kReduceGroup = 64;
+__global__ void k_reduce_partials(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ part_owner,
+                                  const uint32_t* __restrict__ n_partials, const Slot* __restrict__ slots,
+                                  const uint32_t* __restrict__ multi_list, uint32_t num_bins, Bin* __restrict__ multi_bins) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= 21 * num_bins) return;
+  const uint32_t a = w / (7 * num_bins), f = (w / num_bins) % 7, b = w % num_bins;
+  const uint32_t i0 = blockIdx.y * kReduceGroup;
+  const uint32_t total = *n_partials;
+  const uint32_t i1 = i0 + kReduceGroup < total ? i0 + kReduceGroup : total;
+  uint32_t owner = kNone, acc = 0;
+  bool live = false;
+  auto flush = [&]() {
+    if (owner == kNone || acc == 0) return;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(multi_bins + (static_cast<size_t>(owner) * 3 + a) * num_bins + b) + f;
+    if (f == 0) atomicAdd(dst, acc); else raise(dst, acc);
+  };
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t o = part_owner[i];
+    if (o != owner) {
+      flush();
+      owner = o;
+      acc = 0;
+      live = (slots[multi_list[o]].axis_mask >> a & 1u) != 0;
+    }
+    if (live) {
+      const uint32_t v = partials[static_cast<size_t>(i) * 21 * num_bins + w];
+      acc = f == 0 ? acc + v : (acc < v ? v : acc);
+    }
+  }
+  flush();
 }
 
 // One wave per (node with global bins, axis).  Dynamic LDS: 6 * num_bins floats.
@@ -573,9 +648,8 @@ __global__ void k_make_children(const Slot* __restrict__ slots, uint32_t n_slots
 }
 
 // goes_left[k] = 1 when position k moves into the left child (bvh.cpp:120-128)
-__global__ void k_goes_left(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
-                            const BNode* __restrict__ nodes, uint32_t ls, const Slot* __restrict__ slots,
-                            const Choice* __restrict__ choice, const float4* __restrict__ tbox, uint32_t num_bins,
+__global__ void k_goes_left(const uint32_t* __restrict__ node_of, uint32_t n, const BNode* __restrict__ nodes,
+                            uint32_t ls, const Choice* __restrict__ choice, const uint32_t* __restrict__ pbins,
                             uint32_t* __restrict__ goes_left) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -585,15 +659,7 @@ __global__ void k_goes_left(const uint32_t* __restrict__ order, const uint32_t* 
     const uint32_t s = nodes[nd].slot;
     if (s != kNone) {
       const Choice c = choice[s];
-      if (c.axis >= 0) {
-        const Slot& sl = slots[s];
-        const uint32_t t = order[k];
-        const float4 top = tbox[2ull * t], bot = tbox[2ull * t + 1];
-        const float tp = c.axis == 0 ? top.x : (c.axis == 1 ? top.y : top.z);
-        const float bt = c.axis == 0 ? bot.x : (c.axis == 1 ? bot.y : bot.z);
-        const float ctr = (tp + bt) * 0.5f;
-        f = bin_index(ctr, sl.start[c.axis], sl.inv[c.axis], num_bins - 1) <= c.index ? 1u : 0u;
-      }
+      if (c.axis >= 0) f = ((pbins[k] >> (10 * c.axis)) & 1023u) <= c.index ? 1u : 0u;
     }
   }
   goes_left[k] = f;
@@ -779,7 +845,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   const uint64_t cap = max_nodes(n);
 
   DeviceBuffer tbox, order[2], node_of[2], nodes, misc, flags, ranks, slots, items, item_base, multi_list, bins,
-    axis_best, choice, gl, gls, flat_index, tri_offset;
+    partials, part_owner, pbins, axis_best, choice, gl, gls, flat_index, tri_offset;
   BVHB_TRY(tbox.reserve(static_cast<size_t>(n) * 32));
   for (int i = 0; i < 2; i++) {
     BVHB_TRY(order[i].reserve(static_cast<size_t>(n) * 4));
@@ -789,9 +855,10 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(misc.reserve(64));
   BVHB_TRY(gl.reserve(static_cast<size_t>(n) * 4));
   BVHB_TRY(gls.reserve(static_cast<size_t>(n) * 4));
+  BVHB_TRY(pbins.reserve(static_cast<size_t>(n) * 4));
   uint32_t* d_root = misc.as<uint32_t>();      // 6 words
   uint32_t* d_total = misc.as<uint32_t>() + 8; // scan total
-  uint32_t* d_multi_count = misc.as<uint32_t>() + 9;
+  uint32_t* d_multi_count = misc.as<uint32_t>() + 9; // + 10: slabs handed out
   uint32_t* h_total = nullptr;
   BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64));
   struct Pinned {
@@ -848,30 +915,44 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     const uint32_t chunk = 16 * num_bins > 1024 ? 16 * num_bins : 1024;
     const uint32_t max_multi = n / chunk < n_slots ? n / chunk : n_slots; // nodes with more than `chunk` triangles
     const uint32_t max_items = n / chunk + n_slots;
+    const uint32_t max_partials = max_multi ? 2 * (n / chunk) + 1 : 0; // ceil(n_s / chunk) <= 2 n_s / chunk for n_s > chunk
     const size_t n_bins = static_cast<size_t>(max_multi) * 3 * num_bins;
     BVHB_TRY(slots.reserve(static_cast<size_t>(n_slots) * sizeof(Slot)));
     BVHB_TRY(items.reserve(static_cast<size_t>(n_slots) * 4));
     BVHB_TRY(item_base.reserve(static_cast<size_t>(n_slots) * 4));
     BVHB_TRY(multi_list.reserve(static_cast<size_t>(max_multi + 1) * 4));
     BVHB_TRY(bins.reserve(n_bins * sizeof(Bin) + 16));
+    BVHB_TRY(partials.reserve(static_cast<size_t>(max_partials) * 21 * num_bins * 4 + 16));
+    BVHB_TRY(part_owner.reserve(static_cast<size_t>(max_partials) * 4 + 16));
     BVHB_TRY(axis_best.reserve(static_cast<size_t>(n_slots) * 3 * sizeof(AxisBest)));
     BVHB_TRY(choice.reserve(static_cast<size_t>(n_slots) * sizeof(Choice)));
-    peak_bins = n_bins * sizeof(Bin) > peak_bins ? n_bins * sizeof(Bin) : peak_bins;
-    BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 4, stream));
+    const size_t bin_bytes = n_bins * sizeof(Bin) + static_cast<size_t>(max_partials) * 21 * num_bins * 4;
+    peak_bins = bin_bytes > peak_bins ? bin_bytes : peak_bins;
+    BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
     k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
                                             num_bins, chunk, slots.as<Slot>(), items.as<uint32_t>(), d_multi_count,
-                                            multi_list.as<uint32_t>());
+                                            multi_list.as<uint32_t>(), d_multi_count + 1);
     rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>()); // total -> *d_total
     if (rc) return rc;
     if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
-    k_bin_sah<<<max_items, 64, 13 * num_bins * 4, stream>>>(order[cur].as<uint32_t>(), nodes.as<BNode>(),
-                                                           slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total,
-                                                           chunk, tbox.as<float4>(), num_bins, bins.as<Bin>(),
-                                                           axis_best.as<AxisBest>());
-    if (max_multi)
+    if (27 * num_bins * 4 <= 65536) // the bins of three axes and the suffix boxes fit the LDS of one block
+      k_bin_sah<true><<<max_items, 64, 27 * num_bins * 4, stream>>>(
+        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total, chunk,
+        tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
+        axis_best.as<AxisBest>());
+    else
+      k_bin_sah<false><<<max_items, 64, 13 * num_bins * 4, stream>>>(
+        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total, chunk,
+        tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
+        axis_best.as<AxisBest>());
+    if (max_multi) {
+      const dim3 rg((21 * num_bins + kB - 1) / kB, (max_partials + kReduceGroup - 1) / kReduceGroup);
+      k_reduce_partials<<<rg, kB, 0, stream>>>(partials.as<uint32_t>(), part_owner.as<uint32_t>(), d_multi_count + 1,
+                                              slots.as<Slot>(), multi_list.as<uint32_t>(), num_bins, bins.as<Bin>());
       k_sah_multi<<<max_multi * 3, 64, 6 * num_bins * 4, stream>>>(slots.as<Slot>(), multi_list.as<uint32_t>(),
                                                                   d_multi_count, num_bins, bins.as<Bin>(),
                                                                   axis_best.as<AxisBest>());
+    }
     // flags / ranks are reused per slot from here on (n_slots <= m)
     k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
                                               choice.as<Choice>(), flags.as<uint32_t>());
@@ -885,9 +966,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(),
                                                      axis_best.as<AxisBest>(), choice.as<Choice>(),
                                                      ranks.as<uint32_t>(), le);
-    k_goes_left<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n,
-                                           nodes.as<BNode>(), ls, slots.as<Slot>(), choice.as<Choice>(),
-                                           tbox.as<float4>(), num_bins, gl.as<uint32_t>());
+    k_goes_left<<<grid(n), kB, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls, choice.as<Choice>(),
+                                           pbins.as<uint32_t>(), gl.as<uint32_t>());
     rc = scan.run(gl.as<uint32_t>(), n, gls.as<uint32_t>());
     if (rc) return rc;
     k_scatter<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(),
