@@ -263,6 +263,11 @@ uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles);
 int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
                        uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
                        uint32_t* order_out, nova_hip_build_stats* stats /* may be NULL */);
+/* The same with every array in DEVICE memory from nova_hip_malloc (vertices in, the rest out): the
+ * tree is built where nova_hip_launch_raytrace / nova_hip_trace_rays read it, nothing crosses PCIe. */
+int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
+                              uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
+                              uint32_t* order_out, nova_hip_build_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ EXPORTS = [
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
     "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
+    "nova_hip_build_bvh_device",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE = -1, -2, -3, -4, -5
@@ -105,6 +106,7 @@ def load() -> ctypes.CDLL:
         "nova_hip_get_counters": [vp],
         "nova_hip_reset_counters": [],
         "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
+        "nova_hip_build_bvh_device": [vp, u64, vp, u64, vp, vp, vp, vp],
     }
     lib.nova_hip_bvh_max_nodes.restype = u64
     lib.nova_hip_bvh_max_nodes.argtypes = [u64]
@@ -314,3 +316,17 @@ def build_bvh(verts: np.ndarray):
                                  order.ctypes.data, ctypes.byref(stats)))
     return bvh[: n_nodes.value].copy(), tris, order, {"device_ms": stats.device_ms, "levels": stats.levels,
                                                      "peak_bin_bytes": stats.peak_bin_bytes}
+
+
+def build_bvh_device(verts: "Buffer", n: int):
+    """nova_hip_build_bvh_device: verts is a device Buffer of n*9 floats.  Returns (bvh Buffer, triangles
+    Buffer, order Buffer, n_nodes, stats dict); nothing leaves the device."""
+    lib = load()
+    cap = int(lib.nova_hip_bvh_max_nodes(n))
+    bvh, tris, order = Buffer(nbytes=cap * 32), Buffer(nbytes=n * 48), Buffer(nbytes=n * 4)
+    n_nodes = ctypes.c_uint64(0)
+    stats = BuildStats()
+    check(lib.nova_hip_build_bvh_device(verts.ptr, n, bvh.ptr, cap, ctypes.byref(n_nodes), tris.ptr, order.ptr,
+                                        ctypes.byref(stats)))
+    return bvh, tris, order, int(n_nodes.value), {"device_ms": stats.device_ms, "levels": stats.levels,
+                                                  "peak_bin_bytes": stats.peak_bin_bytes}

@@ -409,7 +409,7 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
 // binned in one pass over the triangles (21 * num_bins words of bins); otherwise one pass per axis.
 template <bool FUSED>
 __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ order, const BNode* __restrict__ nodes,
-                                                const Slot* __restrict__ slots, uint32_t n_slots,
+                                                const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
                                                 const uint32_t* __restrict__ item_base,
                                                 const uint32_t* __restrict__ n_items_ptr, uint32_t chunk,
                                                 const float4* __restrict__ tbox, uint32_t num_bins,
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
   if (item >= *n_items_ptr) return;
   const uint32_t lane = threadIdx.x;
   // the slot whose items include `item`: last s with item_base[s] <= item (every slot has >= 1 item)
-  uint32_t lo = 0, hi = n_slots - 1;
+  uint32_t lo = 0, hi = *n_slots_ptr - 1;
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (item_base[mid] <= item) lo = mid; else hi = mid - 1;
@@ -588,11 +588,15 @@ __global__ void __launch_bounds__(64) k_sah_multi(const Slot* __restrict__ slots
 }
 
 // bvh.cpp:141-142, 184-190: the best of the node's own cost and the three axes, later wins a tie
-__global__ void k_choose(const Slot* __restrict__ slots, uint32_t n_slots, const BNode* __restrict__ nodes,
-                         const AxisBest* __restrict__ axis_best, Choice* __restrict__ choice,
-                         uint32_t* __restrict__ split_flag) {
+__global__ void k_choose(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr, uint32_t bound,
+                         const BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
+                         Choice* __restrict__ choice, uint32_t* __restrict__ split_flag) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
+  if (s >= bound) return;
+  if (s >= *n_slots_ptr) {
+    split_flag[s] = 0;
+    return;
+  }
   const Slot& sl = slots[s];
   const BNode& nd = nodes[sl.node];
   float best_cost = cost(nd.top, nd.bot, sl.n);
@@ -616,11 +620,12 @@ __global__ void k_choose(const Slot* __restrict__ slots, uint32_t n_slots, const
 }
 
 // bvh.cpp:107-118: the two child records
-__global__ void k_make_children(const Slot* __restrict__ slots, uint32_t n_slots, BNode* __restrict__ nodes,
-                                const AxisBest* __restrict__ axis_best, Choice* __restrict__ choice,
-                                const uint32_t* __restrict__ split_rank, uint32_t level_end) {
+__global__ void k_make_children(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
+                                BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
+                                Choice* __restrict__ choice, const uint32_t* __restrict__ split_rank,
+                                uint32_t level_end) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
+  if (s >= *n_slots_ptr) return;
   Choice& c = choice[s];
   if (c.axis < 0) return;
   BNode& nd = nodes[slots[s].node];
@@ -821,11 +826,11 @@ struct Scanner {
   uint32_t* d_total = nullptr; // device word
   hipStream_t stream = nullptr;
   // out[i] = sum of in[0..i); the total lands in *d_total
-  int run(const uint32_t* in, uint32_t n, uint32_t* out) {
+  int run(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* total = nullptr) {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
     BVHB_TRY(sums.reserve(static_cast<size_t>(nb) * 4));
     k_scan_reduce<<<nb, kScanBlock, 0, stream>>>(in, n, sums.as<uint32_t>());
-    k_scan_sums<<<1, kScanBlock, 0, stream>>>(sums.as<uint32_t>(), nb, d_total);
+    k_scan_sums<<<1, kScanBlock, 0, stream>>>(sums.as<uint32_t>(), nb, total ? total : d_total);
     k_scan_apply<<<nb, kScanBlock, 0, stream>>>(in, n, sums.as<uint32_t>(), out);
     return static_cast<int>(hipGetLastError());
   }
@@ -859,6 +864,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   uint32_t* d_root = misc.as<uint32_t>();      // 6 words
   uint32_t* d_total = misc.as<uint32_t>() + 8; // scan total
   uint32_t* d_multi_count = misc.as<uint32_t>() + 9; // + 10: slabs handed out
+  uint32_t* d_n_slots = misc.as<uint32_t>() + 11;
+  uint32_t* d_n_items = misc.as<uint32_t>() + 12;
   uint32_t* h_total = nullptr;
   BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64));
   struct Pinned {
@@ -904,12 +911,10 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     BVHB_TRY(flags.reserve(static_cast<size_t>(m) * 4));
     BVHB_TRY(ranks.reserve(static_cast<size_t>(m) * 4));
     k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>());
-    int rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>());
+    // the number of nodes to split stays on the device (d_n_slots); the host sizes everything by m
+    int rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>(), d_n_slots);
     if (rc) return rc;
-    uint32_t n_slots = 0;
-    rc = read_total(&n_slots);
-    if (rc) return rc;
-    if (n_slots == 0) break;
+    const uint32_t n_slots = m; // upper bound
 
     // work items: `chunk` consecutive positions of one node; a node of more than one item has global bins
     const uint32_t chunk = 16 * num_bins > 1024 ? 16 * num_bins : 1024;
@@ -929,20 +934,21 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     const size_t bin_bytes = n_bins * sizeof(Bin) + static_cast<size_t>(max_partials) * 21 * num_bins * 4;
     peak_bins = bin_bytes > peak_bins ? bin_bytes : peak_bins;
     BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
+    BVHB_TRY(hipMemsetAsync(items.p, 0, static_cast<size_t>(m) * 4, stream)); // nodes that are not split: no items
     k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
                                             num_bins, chunk, slots.as<Slot>(), items.as<uint32_t>(), d_multi_count,
                                             multi_list.as<uint32_t>(), d_multi_count + 1);
-    rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>()); // total -> *d_total
+    rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>(), d_n_items);
     if (rc) return rc;
     if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
     if (27 * num_bins * 4 <= 65536) // the bins of three axes and the suffix boxes fit the LDS of one block
       k_bin_sah<true><<<max_items, 64, 27 * num_bins * 4, stream>>>(
-        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total, chunk,
+        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
         tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
         axis_best.as<AxisBest>());
     else
       k_bin_sah<false><<<max_items, 64, 13 * num_bins * 4, stream>>>(
-        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), n_slots, item_base.as<uint32_t>(), d_total, chunk,
+        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
         tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
         axis_best.as<AxisBest>());
     if (max_multi) {
@@ -954,8 +960,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
                                                                   axis_best.as<AxisBest>());
     }
     // flags / ranks are reused per slot from here on (n_slots <= m)
-    k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
-                                              choice.as<Choice>(), flags.as<uint32_t>());
+    k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, n_slots, nodes.as<BNode>(),
+                                              axis_best.as<AxisBest>(), choice.as<Choice>(), flags.as<uint32_t>());
     rc = scan.run(flags.as<uint32_t>(), n_slots, ranks.as<uint32_t>());
     if (rc) return rc;
     uint32_t n_split = 0;
@@ -963,7 +969,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     if (rc) return rc;
     if (n_split == 0) break;
     if (static_cast<uint64_t>(le) + 2ull * n_split > cap) return NOVA_HIP_E_BAD_SCENE; // cannot happen
-    k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), n_slots, nodes.as<BNode>(),
+    k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, nodes.as<BNode>(),
                                                      axis_best.as<AxisBest>(), choice.as<Choice>(),
                                                      ranks.as<uint32_t>(), le);
     k_goes_left<<<grid(n), kB, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls, choice.as<Choice>(),

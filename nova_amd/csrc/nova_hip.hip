@@ -1137,6 +1137,39 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
 
 uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles) { return bvhb::max_nodes(num_triangles); }
 
+int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
+                              uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
+                              uint32_t* order_out, nova_hip_build_stats* stats) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!vertices || !bvh_out || !num_nodes || !triangles_out || !order_out || num_triangles == 0)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (num_triangles > (1ull << 24)) return NOVA_HIP_E_TOO_LARGE;
+  if (bvh_capacity < bvhb::max_nodes(num_triangles)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const Alloc* av = find_alloc(vertices);
+  const Alloc* ab = find_alloc(bvh_out);
+  const Alloc* at = find_alloc(triangles_out);
+  const Alloc* ao = find_alloc(order_out);
+  if (!av || !ab || !at || !ao) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  if (av->bytes < num_triangles * 36 || ab->bytes < bvh_capacity * sizeof(nova_bvh_node) ||
+      at->bytes < num_triangles * sizeof(nova_triangle_data) || ao->bytes < num_triangles * 4)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  bvhb::Result res;
+  rc = bvhb::build(g.stream, vertices, static_cast<uint32_t>(num_triangles), bvh_out, triangles_out, order_out, &res);
+  if (rc) return rc;
+  // the scene cache keys on pointer + version: new contents in these buffers
+  touch(bvh_out);
+  touch(triangles_out);
+  touch(order_out);
+  *num_nodes = res.n_nodes;
+  if (stats) {
+    stats->device_ms = res.device_ms;
+    stats->levels = res.levels;
+    stats->peak_bin_bytes = res.peak_bin_bytes;
+  }
+  return 0;
+}
+
 int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
                        uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
                        uint32_t* order_out, nova_hip_build_stats* stats) {

@@ -136,3 +136,40 @@ def test_a_scene_built_on_the_device_renders_the_same_frame():
         rt.kernel_raytrace(3)
         frames.append(rt.temp_color_img1.read())
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+
+
+def test_device_resident_build_feeds_trace_rays():
+    """nova_hip_build_bvh_device: nothing crosses PCIe; the buffers it fills are traced directly and give
+    the hits of the CPU-built scene; rebuilding into the same buffers is seen (scene cache versioning)."""
+    from tests.conftest import random_rays
+    results = []
+    bufs = None
+    for seed in (11, 12):
+        verts = S.soup(30000, seed=seed, edge=0.06)
+        host = S.build_scene(verts)
+        if bufs is None:
+            dv = capi.Buffer(verts)
+            bvh, tris, order, n_nodes, stats = capi.build_bvh_device(dv, len(verts))
+            bufs = (dv, bvh, tris, order)
+        else:  # second scene into the SAME device buffers
+            dv, bvh, tris, order = bufs
+            dv.write(verts)
+            lib = capi.load()
+            n = ctypes.c_uint64(0)
+            capi.check(lib.nova_hip_build_bvh_device(dv.ptr, len(verts), bvh.ptr, bvh.nbytes // 32, ctypes.byref(n),
+                                                     tris.ptr, order.ptr, None))
+            n_nodes = int(n.value)
+        assert n_nodes == len(host.bvh)
+        got = bvh.read(S.BVH_NODE, n_nodes)
+        for f in ("top_offset_left", "bottom_num_right"):
+            np.testing.assert_array_equal(got[f], host.bvh[f])
+        np.testing.assert_array_equal(order.read(np.uint32, len(verts)), host.tri_order)
+        o, d = random_rays(20000, seed=seed)
+        ro, rd, hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=len(o) * 16)
+        capi.trace_rays(tris, bvh, ro, rd, hits, len(o))
+        dev_hits = hits.read(np.float32).reshape(-1, 4).copy()
+        hb, ht = capi.Buffer(host.bvh), capi.Buffer(host.triangles)
+        capi.trace_rays(ht, hb, ro, rd, hits, len(o))
+        np.testing.assert_array_equal(dev_hits.view(np.uint32), hits.read(np.float32).reshape(-1, 4).view(np.uint32))
+        results.append(dev_hits)
+    assert not np.array_equal(results[0], results[1])
