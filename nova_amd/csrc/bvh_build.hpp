@@ -306,6 +306,50 @@ __device__ __forceinline__ CountBox shuffle_from(const CountBox& v, int src_lane
   return o;
 }
 
+// Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves (no LDS traffic):
+// row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3
+// (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).  A lane without a source gets the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step(CountBox& v) {
+  CountBox o;
+  o.n = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v.n), CTRL, ROW_MASK, 0xf, false));
+  for (int j = 0; j < 3; j++) {
+    o.box.top[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-kFltMax), __float_as_int(v.box.top[j]),
+                                                              CTRL, ROW_MASK, 0xf, false));
+    o.box.bot[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(kFltMax), __float_as_int(v.box.bot[j]),
+                                                              CTRL, ROW_MASK, 0xf, false));
+  }
+  combine(v, o);
+}
+__device__ __forceinline__ void wave_scan(CountBox& v) {
+  scan_step<0x111, 0xf>(v);
+  scan_step<0x112, 0xf>(v);
+  scan_step<0x114, 0xf>(v);
+  scan_step<0x118, 0xf>(v);
+  scan_step<0x142, 0xa>(v);
+  scan_step<0x143, 0xc>(v);
+}
+__device__ __forceinline__ CountBox last_lane(const CountBox& v) {
+  CountBox o;
+  o.n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v.n), 63));
+  for (int j = 0; j < 3; j++) {
+    o.box.top[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.box.top[j]), 63));
+    o.box.bot[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.box.bot[j]), 63));
+  }
+  return o;
+}
+// the better of two (cost, index) pairs: smaller cost, the later split on a tie (SplitParams::min, bvh.hpp)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best_step(float& key, uint32_t& idx) {
+  const float ok = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(__builtin_inff()), __float_as_int(key), CTRL,
+                                                              ROW_MASK, 0xf, false));
+  const uint32_t oi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(idx), CTRL, ROW_MASK, 0xf, false));
+  if (ok < key || (ok == key && oi > idx)) {
+    key = ok;
+    idx = oi;
+  }
+}
+
 // `load(b)` returns bin b (b < num_bins).  rb: 6 * num_bins floats of LDS, rb[j * num_bins + b].
 // All 64 lanes of the wave call this; lane 0 writes *out.
 template <class Load>
@@ -315,19 +359,16 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
   // right_bounds[b] = box of bins b .. num_bins-1
   CountBox carry = empty_count_box();
   for (uint32_t c = chunks; c-- > 0;) {
-    const uint32_t b = c * 64 + lane;
+    const uint32_t b = c * 64 + (63 - lane); // bins right to left over the lanes: a suffix is a prefix scan
     CountBox v = b < num_bins ? load(b) : empty_count_box();
-    for (int d = 1; d < 64; d <<= 1) {
-      const CountBox o = shuffle_from(v, lane + d < 64 ? lane + d : lane);
-      if (lane + d < 64) combine(v, o);
-    }
+    wave_scan(v);
     combine(v, carry);
     if (b < num_bins)
       for (int j = 0; j < 3; j++) {
         rb[j * num_bins + b] = v.box.top[j];
         rb[(3 + j) * num_bins + b] = v.box.bot[j];
       }
-    carry = shuffle_from(v, 0);
+    carry = last_lane(v);
   }
   __syncthreads(); // the block is this one wave: its LDS writes above are visible to its reads below
   // left_bounds[s] = box of bins 0 .. s; every split s < num_bins - 1 in its own lane
@@ -340,10 +381,7 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
   for (uint32_t c = 0; c < chunks; c++) {
     const uint32_t s = c * 64 + lane;
     CountBox v = s < num_bins ? load(s) : empty_count_box();
-    for (int d = 1; d < 64; d <<= 1) {
-      const CountBox o = shuffle_from(v, lane >= d ? lane - d : lane);
-      if (lane >= d) combine(v, o);
-    }
+    wave_scan(v);
     // carry first, as the sequential loop grows left to right (only the sign of a zero could differ)
     CountBox left = carry;
     combine(left, v);
@@ -366,19 +404,19 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
         }
       }
     }
-    carry = shuffle_from(left, 63);
+    carry = last_lane(left);
   }
   // smallest cost, the later split on a tie (SplitParams::min, bvh.hpp)
   float key = has ? best_cost : __builtin_inff();
   uint32_t idx = best_index;
-  for (int d = 32; d > 0; d >>= 1) {
-    const float ok = __shfl_xor(key, d, 64);
-    const uint32_t oi = __shfl_xor(idx, d, 64);
-    if (ok < key || (ok == key && oi > idx)) {
-      key = ok;
-      idx = oi;
-    }
-  }
+  best_step<0x111, 0xf>(key, idx);
+  best_step<0x112, 0xf>(key, idx);
+  best_step<0x114, 0xf>(key, idx);
+  best_step<0x118, 0xf>(key, idx);
+  best_step<0x142, 0xa>(key, idx);
+  best_step<0x143, 0xc>(key, idx);
+  key = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), 63)); // lane 63 holds the best of all
+  idx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(idx), 63));
   const bool any = key != __builtin_inff();
   if (any && has && best_index == idx && best_cost == key) {
     AxisBest r;
