@@ -258,6 +258,7 @@ typedef struct {
   float device_ms;         /* device time of the build, without the copies in and out */
   uint32_t levels;         /* tree depth */
   uint64_t peak_bin_bytes; /* largest per-level bin storage */
+  float pack_ms;           /* nova_hip_build_bvh_device: traversal layout from the tree (host clock), 0 if left to the first launch */
 } nova_hip_build_stats;
 uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles);
 int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
@@ -268,6 +269,11 @@ int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_n
 int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
                               uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
                               uint32_t* order_out, nova_hip_build_stats* stats /* may be NULL */);
+/* Validation hook (no counterpart in the reference): the traversal layout cached for these device
+ * buffers — made on the device by nova_hip_build_bvh_device — against the one the host packer makes from
+ * the same FlatBVHNode[]; *different_words = 32-bit words that differ (0 = identical). */
+int nova_hip_validate_scene_pack(const nova_bvh_node* bvh, const nova_triangle_data* triangles,
+                                 uint64_t* different_words);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
     "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
-    "nova_hip_build_bvh_device",
+    "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE = -1, -2, -3, -4, -5
@@ -107,6 +107,7 @@ def load() -> ctypes.CDLL:
         "nova_hip_reset_counters": [],
         "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_build_bvh_device": [vp, u64, vp, u64, vp, vp, vp, vp],
+        "nova_hip_validate_scene_pack": [vp, vp, vp],
     }
     lib.nova_hip_bvh_max_nodes.restype = u64
     lib.nova_hip_bvh_max_nodes.argtypes = [u64]
@@ -295,7 +296,8 @@ def trace_rays(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Bu
 
 
 class BuildStats(ctypes.Structure):
-    _fields_ = [("device_ms", ctypes.c_float), ("levels", ctypes.c_uint32), ("peak_bin_bytes", ctypes.c_uint64)]
+    _fields_ = [("device_ms", ctypes.c_float), ("levels", ctypes.c_uint32), ("peak_bin_bytes", ctypes.c_uint64),
+                ("pack_ms", ctypes.c_float)]
 
 
 def build_bvh(verts: np.ndarray):
@@ -329,4 +331,11 @@ def build_bvh_device(verts: "Buffer", n: int):
     check(lib.nova_hip_build_bvh_device(verts.ptr, n, bvh.ptr, cap, ctypes.byref(n_nodes), tris.ptr, order.ptr,
                                         ctypes.byref(stats)))
     return bvh, tris, order, int(n_nodes.value), {"device_ms": stats.device_ms, "levels": stats.levels,
-                                                  "peak_bin_bytes": stats.peak_bin_bytes}
+                                                  "peak_bin_bytes": stats.peak_bin_bytes, "pack_ms": stats.pack_ms}
+
+
+def validate_scene_pack(bvh: "Buffer", tris: "Buffer") -> int:
+    """Words in which the cached (device-made) traversal layout differs from the host packer's."""
+    d = ctypes.c_uint64(0)
+    check(load().nova_hip_validate_scene_pack(bvh.ptr, tris.ptr, ctypes.byref(d)))
+    return int(d.value)

@@ -14,8 +14,8 @@
 //   k_bin_sah    one wave per work item = up to `chunk` consecutive triangle positions of ONE node: bin
 //                index per axis, counts and boxes accumulated in LDS.  A node that fits one item (all the
 //                deep levels) is evaluated on the spot, bins never leaving LDS; a larger node's items
-//                add their LDS bins to the node's global bins (one atomic per non-empty bin per item
-//                instead of seven per triangle)
+//                store their LDS bins to slabs that k_reduce_partials sums into the node's global bins
+//                (no contended atomics per triangle)
 //   k_sah_multi  one wave per (large node, axis): the same evaluation over the global bins
 //                (evaluation = suffix boxes, prefix boxes and counts by wave scans, cost of every split
 //                in its own lane, minimum with the later split winning a tie)
@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "nova_hip.h"
@@ -746,11 +747,12 @@ __global__ void k_sizes(BNode* __restrict__ nodes, uint32_t ls, uint32_t m) {
 }
 
 // flat_index / tri_offset of the children, and the node's own flat record
-__global__ void k_flatten(const BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t* __restrict__ flat_index,
+// (a node's children are left in visiting order: left = first)
+__global__ void k_flatten(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t* __restrict__ flat_index,
                           uint32_t* __restrict__ tri_offset, nova_bvh_node* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  const BNode& nd = nodes[ls + i];
+  BNode& nd = nodes[ls + i];
   const uint32_t me = flat_index[ls + i], toff = tri_offset[ls + i];
   nova_bvh_node f;
   f.top_offset_left = { nd.top[0], nd.top[1], nd.top[2], 0.0f };
@@ -765,6 +767,8 @@ __global__ void k_flatten(const BNode* __restrict__ nodes, uint32_t ls, uint32_t
     if (surface_area(r.top, r.bot) > surface_area(l.top, l.bot)) { // visit the larger child first
       first = nd.right;
       second = nd.left;
+      nd.left = first;
+      nd.right = second;
     }
     const BNode& fn = nodes[first];
     flat_index[first] = me + 1;
@@ -833,6 +837,20 @@ __global__ void k_emit_triangles(const uint32_t* __restrict__ order, const uint3
 struct DeviceBuffer {
   void* p = nullptr;
   size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) {
+      (void) hipFree(p);
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
   ~DeviceBuffer() { (void) hipFree(p); }
   hipError_t reserve(size_t want) {
     if (want <= bytes) return hipSuccess;
@@ -877,12 +895,22 @@ struct Scanner {
 struct Result {
   uint32_t n_nodes = 0, levels = 0;
   float device_ms = 0.0f;
+  float pack_ms = 0.0f; // traversal layout made from the tree (bvh_pack_device.hpp), host clock
   size_t peak_bin_bytes = 0;
+};
+
+// The builder's own tree, for a caller that goes on with it on the device (bvh_pack_device.hpp)
+struct Tree {
+  DeviceBuffer nodes;               // BNode[n_nodes]; left = the child visited first
+  DeviceBuffer flat_index;          // index of each node in the FlatBVHNode array
+  DeviceBuffer tri_offset;          // first triangle (output order) of each node's subtree
+  std::vector<uint32_t> level_start; // nodes of depth d: [level_start[d], level_start[d + 1])
+  uint32_t n_nodes = 0;
 };
 
 // d_verts: n*9 floats on the device.  d_bvh: room for max_nodes(n) records.  d_tris, d_tri_order: n.
 inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_node* d_bvh,
-                 nova_triangle_data* d_tris, uint32_t* d_tri_order, Result* result) {
+                 nova_triangle_data* d_tris, uint32_t* d_tri_order, Result* result, Tree* keep = nullptr) {
   constexpr uint32_t kB = 256;
   auto grid = [](uint64_t items) { return static_cast<uint32_t>((items + kB - 1) / kB); };
   const uint64_t cap = max_nodes(n);
@@ -1048,6 +1076,13 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     result->levels = n_levels;
     result->peak_bin_bytes = peak_bins;
     BVHB_TRY(hipEventElapsedTime(&result->device_ms, ev0, ev1));
+  }
+  if (keep) {
+    keep->nodes = std::move(nodes);
+    keep->flat_index = std::move(flat_index);
+    keep->tri_offset = std::move(tri_offset);
+    keep->level_start = level_start;
+    keep->n_nodes = n_nodes;
   }
   return 0;
 }

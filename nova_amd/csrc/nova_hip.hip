@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 
 #include "bvh_build.hpp"
 #include "bvh_pack.hpp"
+#include "bvh_pack_device.hpp"
 #include "image_kernels.hpp"
 #include "nova_hip.h"
 #include "shade.hpp"
@@ -299,6 +301,9 @@ int build_quad_layout(const Packer& pk, const std::vector<Node128>& wide, Packed
   return 0;
 }
 
+int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
+                    bool want_quad, PackedScene& s);
+
 int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedScene** out) {
   const Alloc* ab = find_alloc(bvh);
   const Alloc* at = find_alloc(tris);
@@ -313,6 +318,17 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
     }
   }
   drop_scenes_using(bvh); // stale entries for a rewritten buffer
+  PackedScene s;
+  const int rc = pack_scene_host(bvh, tris, ab, at, want_quad, s);
+  if (rc) return rc;
+  g.scenes.push_back(s);
+  *out = &g.scenes.back();
+  return 0;
+}
+
+// The traversal layout of a FlatBVHNode[] in device memory, made on the host (bvh_pack.hpp)
+int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
+                    bool want_quad, PackedScene& s) {
   const size_t n_nodes = ab->bytes / sizeof(nova_bvh_node);
   const size_t n_tris = at->bytes / sizeof(nova_triangle_data);
   if (n_nodes == 0 || n_tris == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -378,7 +394,6 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
     pk.out[n].c.w = e + e_round;
   }
 
-  PackedScene s;
   s.quad_tried = want_quad;
   s.bvh_ptr = bvh;
   s.tri_ptr = tris;
@@ -406,8 +421,6 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
     free_scene(s);
     return static_cast<int>(e);
   }
-  g.scenes.push_back(s);
-  *out = &g.scenes.back();
   return 0;
 }
 
@@ -1155,17 +1168,51 @@ int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nov
       at->bytes < num_triangles * sizeof(nova_triangle_data) || ao->bytes < num_triangles * 4)
     return NOVA_HIP_E_INVALID_ARGUMENT;
   bvhb::Result res;
-  rc = bvhb::build(g.stream, vertices, static_cast<uint32_t>(num_triangles), bvh_out, triangles_out, order_out, &res);
+  bvhb::Tree tree;
+  rc = bvhb::build(g.stream, vertices, static_cast<uint32_t>(num_triangles), bvh_out, triangles_out, order_out, &res,
+                   &tree);
   if (rc) return rc;
   // the scene cache keys on pointer + version: new contents in these buffers
   touch(bvh_out);
   touch(triangles_out);
   touch(order_out);
+  drop_scenes_using(bvh_out);
+  drop_scenes_using(triangles_out);
+  // the traversal layout from the builder's own tree, so that the first launch does not repack on the host
+  static const bool host_pack = std::getenv("NOVA_HIP_HOST_PACK") != nullptr; // diagnostics
+  if (!host_pack && tree.level_start.size() - 1 <= 65) {
+    packdev::Packed pd;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = packdev::pack(g.stream, tree, reinterpret_cast<const float4*>(triangles_out), &pd);
+    if (rc < 0 || rc > 1) return rc;
+    if (rc == 0) {
+      PackedScene s;
+      s.bvh_ptr = bvh_out;
+      s.tri_ptr = triangles_out;
+      s.bvh_version = find_alloc(bvh_out)->version;
+      s.tri_version = find_alloc(triangles_out)->version;
+      s.nodes = pd.nodes;
+      s.wide = pd.wide;
+      s.n_wide = pd.n_wide;
+      s.n_packed = pd.n_packed;
+      s.n_tris = static_cast<uint32_t>(at->bytes / sizeof(nova_triangle_data));
+      s.stack_need = pd.stack_need;
+      s.stack_need_wide = pd.stack_need_wide;
+      s.radius = pd.radius;
+      for (int a = 0; a < 3; a++) {
+        s.root_top[a] = pd.root_top[a];
+        s.root_bot[a] = pd.root_bot[a];
+      }
+      g.scenes.push_back(s);
+      res.pack_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
   *num_nodes = res.n_nodes;
   if (stats) {
     stats->device_ms = res.device_ms;
     stats->levels = res.levels;
     stats->peak_bin_bytes = res.peak_bin_bytes;
+    stats->pack_ms = res.pack_ms;
   }
   return 0;
 }
@@ -1202,7 +1249,49 @@ int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_n
     stats->device_ms = res.device_ms;
     stats->levels = res.levels;
     stats->peak_bin_bytes = res.peak_bin_bytes;
+    stats->pack_ms = res.pack_ms;
   }
+  return 0;
+}
+
+int nova_hip_validate_scene_pack(const nova_bvh_node* bvh, const nova_triangle_data* triangles,
+                                 uint64_t* different_words) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!bvh || !triangles || !different_words) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const Alloc* ab = find_alloc(bvh);
+  const Alloc* at = find_alloc(triangles);
+  if (!ab || !at) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  const PackedScene* have = nullptr;
+  for (const auto& s : g.scenes)
+    if (s.bvh_ptr == bvh && s.tri_ptr == triangles && s.bvh_version == ab->version && s.tri_version == at->version)
+      have = &s;
+  if (!have) return NOVA_HIP_E_INVALID_ARGUMENT; // nothing cached for these buffers
+  PackedScene ref;
+  rc = pack_scene_host(bvh, triangles, ab, at, false, ref);
+  if (rc) return rc;
+  uint64_t diff = 0;
+  diff += have->n_packed != ref.n_packed;
+  diff += have->n_wide != ref.n_wide;
+  diff += have->stack_need != ref.stack_need;
+  diff += have->stack_need_wide != ref.stack_need_wide;
+  diff += have->n_tris != ref.n_tris;
+  diff += __builtin_bit_cast(uint32_t, have->radius) != __builtin_bit_cast(uint32_t, ref.radius);
+  diff += (have->wide == nullptr) != (ref.wide == nullptr);
+  auto compare = [&](const void* a, const void* b, size_t bytes) -> int {
+    std::vector<uint32_t> ha(bytes / 4), hb(bytes / 4);
+    HIP_TRY(hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ha.size(); i++) diff += ha[i] != hb[i];
+    return 0;
+  };
+  if (diff == 0) {
+    rc = compare(have->nodes, ref.nodes, static_cast<size_t>(ref.n_packed) * sizeof(Node64));
+    if (rc == 0 && ref.wide) rc = compare(have->wide, ref.wide, static_cast<size_t>(ref.n_wide) * sizeof(Node128));
+  }
+  free_scene(ref);
+  if (rc) return rc;
+  *different_words = diff;
   return 0;
 }
 

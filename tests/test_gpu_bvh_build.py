@@ -173,3 +173,56 @@ def test_device_resident_build_feeds_trace_rays():
         np.testing.assert_array_equal(dev_hits.view(np.uint32), hits.read(np.float32).reshape(-1, 4).view(np.uint32))
         results.append(dev_hits)
     assert not np.array_equal(results[0], results[1])
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup9", "soup300", "soup30k", "knot96", "room", "needles", "grid"])
+def test_traversal_layout_made_on_the_device_equals_the_host_packer(name):
+    """nova_hip_build_bvh_device also makes the traversal layout (box-pair and four-wide nodes, cull
+    slacks, stack needs) from the builder's tree; nova_hip_validate_scene_pack re-makes it with the host
+    packer from the FlatBVHNode[] and counts the words that differ."""
+    rng = np.random.default_rng(5)
+    if name == "cornell":
+        v = golden("cornell_box.npz")["verts"]
+    elif name.startswith("soup"):
+        n = {"soup9": 9, "soup300": 300, "soup30k": 30000}[name]
+        v = S.soup(n, seed=n, edge=0.3 if n < 1000 else 0.05)
+    elif name == "knot96":
+        v = S.knot_mesh(96, 96)
+    elif name == "room":
+        v = S.room_scene(n_objects=20, res=9)[0]
+    elif name == "needles":
+        c = rng.uniform(-1, 1, (20000, 1, 3)).astype(np.float32)
+        d = rng.normal(size=(20000, 1, 3)).astype(np.float32)
+        t = np.array([0.0, 0.5, 1.0], np.float32).reshape(1, 3, 1) * np.float32(0.6)
+        v = (c + d * t + rng.normal(size=(20000, 3, 3)).astype(np.float32) * np.float32(0.002)).reshape(-1, 9)
+    else:
+        g = np.stack(np.meshgrid(np.arange(48, dtype=np.float32), np.arange(48, dtype=np.float32)), -1).reshape(-1, 2)
+        v = np.zeros((len(g), 9), np.float32)
+        v[:, 0:2] = g
+        v[:, 3:5] = g + np.array([1, 0], np.float32)
+        v[:, 6:8] = g + np.array([0, 1], np.float32)
+        v /= np.float32(48.0)
+    v = np.ascontiguousarray(v, np.float32).reshape(-1, 9)
+    dv = capi.Buffer(v)
+    bvh, tris, order, n_nodes, stats = capi.build_bvh_device(dv, len(v))
+    assert stats["pack_ms"] > 0.0  # the layout was made by the build call
+    assert capi.validate_scene_pack(bvh, tris) == 0
+
+
+def test_trees_left_to_the_host_packer_still_trace():
+    """A single leaf and a leaf of more than 128 triangles (the host packer chains it) are not packed on
+    the device: the first launch packs them on the host as before."""
+    from tests.conftest import random_rays
+    one = S.soup(1, seed=1, edge=0.5)
+    for v in (S.soup(5, seed=2, edge=0.4), np.concatenate([np.repeat(one, 200, axis=0), S.soup(300, seed=3, edge=0.2)])):
+        v = np.ascontiguousarray(v, np.float32)
+        host = S.build_scene(v)
+        dv = capi.Buffer(v)
+        bvh, tris, order, n_nodes, stats = capi.build_bvh_device(dv, len(v))
+        assert stats["pack_ms"] == 0.0
+        o, d = random_rays(5000, seed=4)
+        ro, rd, hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=len(o) * 16)
+        capi.trace_rays(tris, bvh, ro, rd, hits, len(o))
+        got = hits.read(np.float32).reshape(-1, 4).copy()
+        capi.trace_rays(capi.Buffer(host.triangles), capi.Buffer(host.bvh), ro, rd, hits, len(o))
+        np.testing.assert_array_equal(got.view(np.uint32), hits.read(np.float32).reshape(-1, 4).view(np.uint32))
