@@ -226,3 +226,17 @@ def test_trees_left_to_the_host_packer_still_trace():
         got = hits.read(np.float32).reshape(-1, 4).copy()
         capi.trace_rays(capi.Buffer(host.triangles), capi.Buffer(host.bvh), ro, rd, hits, len(o))
         np.testing.assert_array_equal(got.view(np.uint32), hits.read(np.float32).reshape(-1, 4).view(np.uint32))
+
+
+def test_random_scenes_short_soak():
+    """A short run of scripts/gpu_soak_build.py (the long run is logged in profiles/r01_soak_build.log:
+    1500 scenes, 37.5 M triangles): soups, surfaces, clusters, needles, flat sets, lattices, duplicates
+    with zeros and wide-range coordinates — same tree, same traversal layout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_soak_build.py"), "120", "100", "100000"],
+                         cwd=root, capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "0 different" in res.stdout.splitlines()[-1]
