@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "backend/hip/accelerator/accelerator.hpp"
+#include "backend/hip/bvh.hpp"
 
 using namespace nova;
 
@@ -88,6 +89,34 @@ int main(int argc, char** argv) {
     auto triangle_meta_data = slurp<TriangleMetaData>(dir + "/meta.bin");
     auto bvh_data = slurp<FlatBVHNode>(dir + "/bvh.bin");
     auto light_data = slurp<AreaLightData>(dir + "/lights.bin", false);
+    // optional: the model's vertices; then the BVH and the Woop matrices are ALSO built on the device
+    // (backend/hip/bvh.hpp) and must equal the ones read from the files, which the CPU builder made
+    auto vertices = slurp<float>(dir + "/verts.bin", false);
+    if (!vertices.empty()) {
+      DeviceBuiltBVH built = build_bvh(vertices);
+      bool same = built.bvh.size() == bvh_data.size() && built.triangle_data.size() == triangle_data.size();
+      for (size_t i = 0; same && i < bvh_data.size(); i++) {
+        const float* a = reinterpret_cast<const float*>(&built.bvh[i]);
+        const float* b = reinterpret_cast<const float*>(&bvh_data[i]);
+        for (int k = 0; k < 8; k++) same = same && a[k] == b[k];
+      }
+      for (size_t i = 0; same && i < triangle_data.size(); i++) {
+        const float* a = reinterpret_cast<const float*>(&built.triangle_data[i]);
+        const float* b = reinterpret_cast<const float*>(&triangle_data[i]);
+        for (int k = 0; k < 12; k++) same = same && a[k] == b[k];
+      }
+      if (!same) throw std::runtime_error("device-built BVH differs from the CPU builder's");
+      bvh_data = built.bvh; // render with the device-built arrays
+      triangle_data = built.triangle_data;
+      bool threw_empty = false;
+      try {
+        build_bvh({});
+      } catch (const AcceleratorException&) {
+        threw_empty = true;
+      }
+      if (!threw_empty) throw std::runtime_error("empty vertex list did not throw");
+      std::cout << "bvh build OK" << std::endl;
+    }
     auto triangle_buf = accelerator.create_buffer(MemFlags::READ_ONLY, triangle_data);
     auto tri_meta_buf = accelerator.create_buffer(MemFlags::READ_ONLY, triangle_meta_data);
     auto bvh_buf = accelerator.create_buffer(MemFlags::READ_ONLY, bvh_data);

@@ -32,11 +32,15 @@ def test_cpp_accelerator_runs_the_reference_schedule(tmp_path, cornell, denoise)
         os.path.join(d, "image_dims.bin"))
     m.tofile(os.path.join(d, "materials.bin"))
     sky.tofile(os.path.join(d, "sky.bin"))
+    if denoise:  # one of the two runs also builds the BVH on the device through backend/hip/bvh.hpp
+        from tests.helpers import golden
+        np.ascontiguousarray(golden("cornell_box.npz")["verts"], np.float32).tofile(os.path.join(d, "verts.bin"))
     env = dict(os.environ, NOVA_HIP_MAX_DEPTH="4")
     r = subprocess.run([EXE, d, str(w), str(h), str(samples), str(seed), str(denoise)], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest OK" in r.stdout
+    assert ("bvh build OK" in r.stdout) == bool(denoise)
 
     prev = [np.zeros((h, w, 4), np.float32) for _ in range(3)]
     for s in range(samples):
