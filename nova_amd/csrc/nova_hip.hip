@@ -304,6 +304,45 @@ int build_quad_layout(const Packer& pk, const std::vector<Node128>& wide, Packed
 int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
                     bool want_quad, PackedScene& s);
 
+bool host_pack_only() {
+  static const bool on = std::getenv("NOVA_HIP_HOST_PACK") != nullptr; // diagnostics
+  return on;
+}
+
+void adopt_packed(const packdev::Packed& pd, const void* bvh, const void* tris, const Alloc* ab, const Alloc* at,
+                  PackedScene& s) {
+  s.bvh_ptr = bvh;
+  s.tri_ptr = tris;
+  s.bvh_version = ab->version;
+  s.tri_version = at->version;
+  s.nodes = pd.nodes;
+  s.wide = pd.wide;
+  s.n_wide = pd.n_wide;
+  s.n_packed = pd.n_packed;
+  s.n_tris = static_cast<uint32_t>(at->bytes / sizeof(nova_triangle_data));
+  s.stack_need = pd.stack_need;
+  s.stack_need_wide = pd.stack_need_wide;
+  s.radius = pd.radius;
+  for (int a = 0; a < 3; a++) {
+    s.root_top[a] = pd.root_top[a];
+    s.root_bot[a] = pd.root_bot[a];
+  }
+}
+
+// 0: packed on the device; 1: left to the host packer; else an error
+int pack_scene_device(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
+                      PackedScene& s) {
+  const size_t n_alloc = ab->bytes / sizeof(nova_bvh_node);
+  const size_t n_tris = at->bytes / sizeof(nova_triangle_data);
+  if (n_alloc == 0 || n_tris == 0 || n_tris > (1u << 24) || n_alloc > (1u << 26)) return 1;
+  packdev::Packed pd;
+  const int rc = packdev::pack_flat(g.stream, bvh, static_cast<uint32_t>(n_alloc), reinterpret_cast<const float4*>(tris),
+                                    static_cast<uint32_t>(n_tris), &pd);
+  if (rc) return rc < 0 || rc > 1 ? rc : 1;
+  adopt_packed(pd, bvh, tris, ab, at, s);
+  return 0;
+}
+
 int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedScene** out) {
   const Alloc* ab = find_alloc(bvh);
   const Alloc* at = find_alloc(tris);
@@ -319,7 +358,11 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   }
   drop_scenes_using(bvh); // stale entries for a rewritten buffer
   PackedScene s;
-  const int rc = pack_scene_host(bvh, tris, ab, at, want_quad, s);
+  // on the device where the array is a well-formed, nested tree (bvh_pack_device.hpp); else, and for the
+  // experimental quad layout, on the host
+  int rc = 1;
+  if (!host_pack_only() && !want_quad) rc = pack_scene_device(bvh, tris, ab, at, s);
+  if (rc == 1) rc = pack_scene_host(bvh, tris, ab, at, want_quad, s);
   if (rc) return rc;
   g.scenes.push_back(s);
   *out = &g.scenes.back();
@@ -1179,30 +1222,14 @@ int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nov
   drop_scenes_using(bvh_out);
   drop_scenes_using(triangles_out);
   // the traversal layout from the builder's own tree, so that the first launch does not repack on the host
-  static const bool host_pack = std::getenv("NOVA_HIP_HOST_PACK") != nullptr; // diagnostics
-  if (!host_pack && tree.level_start.size() - 1 <= 65) {
+  if (!host_pack_only() && tree.level_start.size() - 1 <= 65) {
     packdev::Packed pd;
     const auto t0 = std::chrono::steady_clock::now();
     rc = packdev::pack(g.stream, tree, reinterpret_cast<const float4*>(triangles_out), &pd);
     if (rc < 0 || rc > 1) return rc;
     if (rc == 0) {
       PackedScene s;
-      s.bvh_ptr = bvh_out;
-      s.tri_ptr = triangles_out;
-      s.bvh_version = find_alloc(bvh_out)->version;
-      s.tri_version = find_alloc(triangles_out)->version;
-      s.nodes = pd.nodes;
-      s.wide = pd.wide;
-      s.n_wide = pd.n_wide;
-      s.n_packed = pd.n_packed;
-      s.n_tris = static_cast<uint32_t>(at->bytes / sizeof(nova_triangle_data));
-      s.stack_need = pd.stack_need;
-      s.stack_need_wide = pd.stack_need_wide;
-      s.radius = pd.radius;
-      for (int a = 0; a < 3; a++) {
-        s.root_top[a] = pd.root_top[a];
-        s.root_bot[a] = pd.root_bot[a];
-      }
+      adopt_packed(pd, bvh_out, triangles_out, find_alloc(bvh_out), at, s);
       g.scenes.push_back(s);
       res.pack_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

@@ -240,3 +240,48 @@ def test_random_scenes_short_soak():
                          cwd=root, capture_output=True, text=True, timeout=200)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "0 different" in res.stdout.splitlines()[-1]
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup2k", "knot96", "room_with_light_and_ground"])
+def test_callers_flat_tree_is_packed_on_the_device_like_the_host_packer(name, monkeypatch):
+    """A FlatBVHNode[] uploaded by the caller (Nova's own host-built tree): the first launch validates it
+    and makes the traversal layout on the device; the host packer must give the same words."""
+    from tests.conftest import random_rays
+    if name == "cornell":
+        sc = S.cornell_box()
+    elif name == "soup2k":
+        sc = S.build_scene(S.soup(2000, seed=2, edge=0.1))
+    elif name == "knot96":
+        sc = S.dragon_standin(96, 96)
+    else:
+        sc = S.dragon_standin(40, 40)
+    bvh, tris = capi.Buffer(sc.bvh), capi.Buffer(sc.triangles)
+    o, d = random_rays(3000, seed=1)
+    ro, rd, hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=len(o) * 16)
+    capi.trace_rays(tris, bvh, ro, rd, hits, len(o))  # packs
+    assert capi.validate_scene_pack(bvh, tris) == 0
+
+
+def test_malformed_flat_trees_still_get_the_host_packers_verdict():
+    sc = S.build_scene(S.soup(500, seed=3, edge=0.2))
+    o = np.zeros((64, 4), np.float32); o[:, 3] = 3e38
+    d = np.zeros((64, 4), np.float32); d[:, 2] = 1
+    ro, rd, hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=64 * 16)
+    tris = capi.Buffer(sc.triangles)
+    cases = []
+    b = sc.bvh.copy(); b["bottom_num_right"][0, 3] = 1.0          # right child = left child
+    cases.append(b)
+    b = sc.bvh.copy(); b["bottom_num_right"][0, 3] = 1e9           # right child out of range
+    cases.append(b)
+    b = sc.bvh.copy()
+    leaf = np.flatnonzero(b["bottom_num_right"][:, 3] < 0)[0]
+    b["top_offset_left"][leaf, 3] = 1e7                             # leaf offset beyond the triangles
+    cases.append(b)
+    for b in cases:
+        with pytest.raises(capi.NovaHipError) as e:
+            capi.trace_rays(tris, capi.Buffer(b), ro, rd, hits, 64)
+        assert e.value.err() == capi.E_BAD_SCENE
+    # a right child that is not where the left subtree ends is no tree in pre-order, but Packer::ref_of does
+    # not check that: the device front end declines it and the host packer walks it as before
+    b = sc.bvh.copy(); b["bottom_num_right"][0, 3] += 1.0
+    capi.trace_rays(tris, capi.Buffer(b), ro, rd, hits, 64)
