@@ -65,7 +65,10 @@ def main():
     rng = np.random.default_rng(20261110)
     capi.init(0)
     t0 = time.time()
-    done = tris_total = packed = bad = 0
+    done = tris_total = packed = bad = uploaded = 0
+    o = np.zeros((64, 4), np.float32); o[:, 3] = 3e38
+    d = np.zeros((64, 4), np.float32); d[:, 2] = 1
+    ray_o, ray_d, ray_hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=64 * 16)
     for i in range(scenes):
         if time.time() - t0 > budget:
             break
@@ -87,6 +90,19 @@ def main():
             different = capi.validate_scene_pack(bvh, tris)
             packed += 1
             ok = different == 0
+        if ok and len(host.bvh) >= 3:
+            # the same tree as a caller's array: uploaded, packed at the first launch, compared again
+            hb, ht = capi.Buffer(host.bvh), capi.Buffer(host.triangles)
+            try:
+                capi.trace_rays(ht, hb, ray_o, ray_d, ray_hits, 64)
+                ok = capi.validate_scene_pack(hb, ht) == 0
+                uploaded += 1
+            except capi.NovaHipError as e:  # deeper than the reference's own stack (with the chains the host
+                # packer makes of leaves above 128 triangles): refused by the host packer, as before
+                big_leaf = float((-host.bvh["bottom_num_right"][:, 3]).max()) > 128
+                ok = e.err() == capi.E_TOO_LARGE and (host.max_depth > 64 or big_leaf)
+            hb.free()
+            ht.free()
         if not ok:
             bad += 1
             np.save(f"gpurun_out/soak_build_bad_{i}.npy", v)
@@ -97,9 +113,9 @@ def main():
         for b_ in (dv, bvh, tris, order):
             b_.free()
         if done % 25 == 0:
-            print(f"{done} scenes, {tris_total} triangles, {packed} layouts compared, {bad} different, "
+            print(f"{done} scenes, {tris_total} triangles, {packed} + {uploaded} layouts compared, {bad} different, "
                   f"{time.time() - t0:.0f} s", flush=True)
-    print(f"soak: {done} scenes, {tris_total} triangles, {packed} layouts compared, {bad} different")
+    print(f"soak: {done} scenes, {tris_total} triangles, {packed} built + {uploaded} uploaded layouts compared, {bad} different")
     return 1 if bad else 0
 
 

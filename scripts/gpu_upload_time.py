@@ -34,3 +34,13 @@ for rep in range(2):
           f"first trace (repack + upload) {t_first * 1e3:.1f} ms, second trace {t_second * 1e3:.2f} ms", flush=True)
     for b in (bvh, tris, order, ro, rd, hits):
         b.free()
+
+# the same scene as a caller's arrays (built on the CPU, uploaded): validation + layout at the first launch
+host = S.build_scene(verts)
+hb, ht = capi.Buffer(host.bvh), capi.Buffer(host.triangles)
+ro, rd, hits = capi.Buffer(o), capi.Buffer(d), capi.Buffer(nbytes=4096 * 16)
+t0 = time.time()
+capi.trace_rays(ht, hb, ro, rd, hits, 4096)
+t_first = time.time() - t0
+print(f"{kind} {n} triangles uploaded as FlatBVHNode[]: first trace (validate + layout) {t_first * 1e3:.1f} ms, "
+      f"words differing from the host packer: {capi.validate_scene_pack(hb, ht)}", flush=True)
