@@ -43,6 +43,8 @@ def test_no_silent_cpu_fallback():
         capi.init(0)
     with pytest.raises(capi.NovaHipError):
         capi.Buffer(np.zeros(4, np.float32))
+    with pytest.raises(capi.NovaHipError):  # the BVH build has no CPU path behind the C ABI either
+        capi.build_bvh(S.soup(20, seed=1, edge=0.3))
 
 
 def test_numpy_layouts_match_c():
