@@ -209,6 +209,28 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t* __restrict__
   if (threadIdx.x == 0) *total = carry;
 }
 
+// the whole scan in one block, for the short arrays of the upper levels (one launch instead of three)
+__global__ void __launch_bounds__(kScanBlock) k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
+  uint32_t carry = 0;
+  for (uint32_t start = 0; start < n; start += kScanTile) {
+    const uint32_t base = start + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], s = 0;
+    for (uint32_t j = 0; j < kScanItems; j++) {
+      v[j] = (base + j < n) ? in[base + j] : 0u;
+      s += v[j];
+    }
+    uint32_t sum;
+    uint32_t ex = carry + block_exclusive(s, &sum);
+    for (uint32_t j = 0; j < kScanItems; j++) {
+      if (base + j < n) out[base + j] = ex;
+      ex += v[j];
+    }
+    carry += sum;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
 __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
                                                             const uint32_t* __restrict__ block_sums,
                                                             uint32_t* __restrict__ out) {
@@ -884,6 +906,10 @@ struct Scanner {
   // out[i] = sum of in[0..i); the total lands in *d_total
   int run(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* total = nullptr) {
     const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    if (nb <= 8) {
+      k_scan_small<<<1, kScanBlock, 0, stream>>>(in, n, out, total ? total : d_total);
+      return static_cast<int>(hipGetLastError());
+    }
     BVHB_TRY(sums.reserve(static_cast<size_t>(nb) * 4));
     k_scan_reduce<<<nb, kScanBlock, 0, stream>>>(in, n, sums.as<uint32_t>());
     k_scan_sums<<<1, kScanBlock, 0, stream>>>(sums.as<uint32_t>(), nb, total ? total : d_total);
