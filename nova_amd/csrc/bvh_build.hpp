@@ -122,22 +122,33 @@ __global__ void k_tri_bounds(const float* __restrict__ verts, uint32_t n, float4
                              uint32_t* __restrict__ root /* 3 enc(max), 3 ~enc(min) */,
                              uint32_t* __restrict__ order, uint32_t* __restrict__ node_of) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = verts + 9ull * i;
-  float top[3], bot[3];
-  for (int a = 0; a < 3; a++) {
-    const float v1 = p[a], v2 = p[3 + a], v3 = p[6 + a];
-    const float m23 = (v2 < v3) ? v3 : v2, n23 = (v3 < v2) ? v3 : v2;
-    top[a] = (v1 < m23) ? m23 : v1;
-    bot[a] = (n23 < v1) ? n23 : v1;
+  uint32_t e[6] = { 0, 0, 0, 0, 0, 0 }; // enc(max) / ~enc(min): 0 = nothing
+  if (i < n) {
+    const float* p = verts + 9ull * i;
+    float top[3], bot[3];
+    for (int a = 0; a < 3; a++) {
+      const float v1 = p[a], v2 = p[3 + a], v3 = p[6 + a];
+      const float m23 = (v2 < v3) ? v3 : v2, n23 = (v3 < v2) ? v3 : v2;
+      top[a] = (v1 < m23) ? m23 : v1;
+      bot[a] = (n23 < v1) ? n23 : v1;
+    }
+    tbox[2ull * i] = make_float4(top[0], top[1], top[2], 0.0f);
+    tbox[2ull * i + 1] = make_float4(bot[0], bot[1], bot[2], 0.0f);
+    order[i] = i;
+    node_of[i] = 0;
+    for (int a = 0; a < 3; a++) {
+      e[a] = enc(top[a]);
+      e[3 + a] = ~enc(bot[a]);
+    }
   }
-  tbox[2ull * i] = make_float4(top[0], top[1], top[2], 0.0f);
-  tbox[2ull * i + 1] = make_float4(bot[0], bot[1], bot[2], 0.0f);
-  order[i] = i;
-  node_of[i] = 0;
-  for (int a = 0; a < 3; a++) {
-    raise(root + a, enc(top[a]));
-    raise(root + 3 + a, ~enc(bot[a]));
+  // one atomic per wave and coordinate instead of one per triangle
+  for (int a = 0; a < 6; a++) {
+    uint32_t v = e[a];
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint32_t o = __shfl_xor(v, d, 64);
+      v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63u) == 0 && v != 0) raise(root + a, v);
   }
 }
 
@@ -1009,7 +1020,12 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     const uint32_t n_slots = m; // upper bound
 
     // work items: `chunk` consecutive positions of one node; a node of more than one item has global bins
-    const uint32_t chunk = 16 * num_bins > 1024 ? 16 * num_bins : 1024;
+    // 16 x bins keeps the slab traffic below the triangles' own; fewer where that would leave the GPU short
+    // of waves (about 2048 items wanted over the whole array)
+    uint32_t chunk = 16 * num_bins;
+    const uint32_t spread = (n / 2048 + 63) & ~63u;
+    if (chunk > spread) chunk = spread;
+    if (chunk < 1024) chunk = 1024;
     const uint32_t max_multi = n / chunk < n_slots ? n / chunk : n_slots; // nodes with more than `chunk` triangles
     const uint32_t max_items = n / chunk + n_slots;
     const uint32_t max_partials = max_multi ? 2 * (n / chunk) + 1 : 0; // ceil(n_s / chunk) <= 2 n_s / chunk for n_s > chunk
