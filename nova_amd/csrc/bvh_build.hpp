@@ -121,9 +121,8 @@ __device__ __forceinline__ Box3 load_bin(const Bin& b) {
 __global__ void k_tri_bounds(const float* __restrict__ verts, uint32_t n, float4* __restrict__ tbox,
                              uint32_t* __restrict__ root /* 3 enc(max), 3 ~enc(min) */,
                              uint32_t* __restrict__ order, uint32_t* __restrict__ node_of) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t e[6] = { 0, 0, 0, 0, 0, 0 }; // enc(max) / ~enc(min): 0 = nothing
-  if (i < n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float* p = verts + 9ull * i;
     float top[3], bot[3];
     for (int a = 0; a < 3; a++) {
@@ -137,18 +136,27 @@ __global__ void k_tri_bounds(const float* __restrict__ verts, uint32_t n, float4
     order[i] = i;
     node_of[i] = 0;
     for (int a = 0; a < 3; a++) {
-      e[a] = enc(top[a]);
-      e[3 + a] = ~enc(bot[a]);
+      const uint32_t et = enc(top[a]), eb = ~enc(bot[a]);
+      e[a] = et > e[a] ? et : e[a];
+      e[3 + a] = eb > e[3 + a] ? eb : e[3 + a];
     }
   }
-  // one atomic per wave and coordinate instead of one per triangle
+  // one atomic per block and coordinate (all six words share a cache line: per-triangle atomics on them
+  // cost more than the rest of the kernel)
+  __shared__ uint32_t part[4][6];
   for (int a = 0; a < 6; a++) {
     uint32_t v = e[a];
     for (int d = 32; d > 0; d >>= 1) {
       const uint32_t o = __shfl_xor(v, d, 64);
       v = o > v ? o : v;
     }
-    if ((threadIdx.x & 63u) == 0 && v != 0) raise(root + a, v);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    uint32_t v = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; w++) v = part[w][threadIdx.x] > v ? part[w][threadIdx.x] : v;
+    if (v != 0) raise(root + threadIdx.x, v);
   }
 }
 
@@ -998,7 +1006,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(hipEventRecord(ev0, stream));
 
   BVHB_TRY(hipMemsetAsync(d_root, 0, 64, stream));
-  k_tri_bounds<<<grid(n), kB, 0, stream>>>(d_verts, n, tbox.as<float4>(), d_root, order[0].as<uint32_t>(),
+  k_tri_bounds<<<grid(n) < 1024u ? grid(n) : 1024u, kB, 0, stream>>>(d_verts, n, tbox.as<float4>(), d_root, order[0].as<uint32_t>(),
                                           node_of[0].as<uint32_t>());
   k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>());
 
