@@ -65,3 +65,16 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(dp, f), errors="replace").read()
                 assert not pat.search(text), os.path.join(dp, f)
+
+
+def test_bvh_node_bound_holds_for_the_cpu_builder():
+    """nova_hip_bvh_max_nodes (no device needed): every split leaves more than two triangles on each side
+    (src/bvh/bvh.cpp:80), so a tree over n triangles has at most 2 * max(1, n // 3) - 1 nodes."""
+    lib = capi.load()
+    for n, seed, edge in ((1, 1, 0.3), (8, 2, 0.3), (9, 3, 0.3), (100, 4, 0.3), (5000, 5, 0.05), (60000, 6, 0.01)):
+        sc = S.build_scene(S.soup(n, seed=seed, edge=edge))
+        bound = int(lib.nova_hip_bvh_max_nodes(n))
+        assert bound == 2 * max(1, n // 3) - 1
+        assert len(sc.bvh) <= bound
+        leaves = sc.bvh["bottom_num_right"][:, 3] < 0
+        assert len(sc.bvh) == 1 or (-sc.bvh["bottom_num_right"][leaves, 3]).min() >= 3
