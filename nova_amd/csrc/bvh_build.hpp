@@ -338,16 +338,6 @@ __device__ __forceinline__ void combine(CountBox& a, const CountBox& b) {
   a.n += b.n;
   grow(a.box, b.box);
 }
-__device__ __forceinline__ CountBox shuffle_from(const CountBox& v, int src_lane) {
-  CountBox o;
-  o.n = __shfl(v.n, src_lane, 64);
-  for (int i = 0; i < 3; i++) {
-    o.box.top[i] = __shfl(v.box.top[i], src_lane, 64);
-    o.box.bot[i] = __shfl(v.box.bot[i], src_lane, 64);
-  }
-  return o;
-}
-
 // Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves (no LDS traffic):
 // row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3
 // (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).  A lane without a source gets the identity.
