@@ -812,7 +812,7 @@ __global__ void k_flatten(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, ui
 }
 
 // Triangle order of the flattened tree and the Woop matrices:
-// rows 0..2 of inverse([e1 e2 n-v1 v1; 0 0 0 1]) (intersectable_manager.cpp:129-145), by cofactors
+// rows 0..2 of glm::inverse([e1 e2 n-v1 v1; 0 0 0 1]) (intersectable_manager.cpp:129-145)
 __global__ void k_emit_triangles(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
                                  const BNode* __restrict__ nodes, const uint32_t* __restrict__ tri_offset,
                                  const float* __restrict__ verts, uint32_t* __restrict__ tri_order,
@@ -832,35 +832,55 @@ __global__ void k_emit_triangles(const uint32_t* __restrict__ order, const uint3
   }
   float nr[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
   const float inv_len = 1.0f / sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+  // glm::inverse(mat4) in glm's own operation order (include/glm/detail/func_matrix.inl:294-352);
+  // m[c][r]: columns (e1,0) (e2,0) (n-v1,0) (v1,1)
   float m[4][4];
   for (int a = 0; a < 3; a++) {
-    m[a][0] = e1[a];
-    m[a][1] = e2[a];
-    m[a][2] = nr[a] * inv_len - v1[a];
-    m[a][3] = v1[a];
+    m[0][a] = e1[a];
+    m[1][a] = e2[a];
+    m[2][a] = nr[a] * inv_len - v1[a];
+    m[3][a] = v1[a];
   }
-  m[3][0] = m[3][1] = m[3][2] = 0.0f;
+  m[0][3] = m[1][3] = m[2][3] = 0.0f;
   m[3][3] = 1.0f;
-  float cof[4][4];
+  const float c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+  const float c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+  const float c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+  const float c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+  const float c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+  const float c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+  const float c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+  const float c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+  const float c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  const float c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+  const float c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+  const float c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+  const float c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+  const float c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+  const float c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+  const float c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+  const float c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+  const float c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+  const float fac0[4] = { c00, c00, c02, c03 }, fac1[4] = { c04, c04, c06, c07 }, fac2[4] = { c08, c08, c10, c11 };
+  const float fac3[4] = { c12, c12, c14, c15 }, fac4[4] = { c16, c16, c18, c19 }, fac5[4] = { c20, c20, c22, c23 };
+  const float vec0[4] = { m[1][0], m[0][0], m[0][0], m[0][0] }, vec1[4] = { m[1][1], m[0][1], m[0][1], m[0][1] };
+  const float vec2[4] = { m[1][2], m[0][2], m[0][2], m[0][2] }, vec3[4] = { m[1][3], m[0][3], m[0][3], m[0][3] };
+  const float sign_a[4] = { 1.0f, -1.0f, 1.0f, -1.0f }, sign_b[4] = { -1.0f, 1.0f, -1.0f, 1.0f };
+  float inv[4][4];
+#pragma unroll
   for (int r = 0; r < 4; r++) {
-    for (int c = 0; c < 4; c++) {
-      int rr[3], cc[3];
-      for (int i = 0, q = 0; i < 4; i++)
-        if (i != r) rr[q++] = i;
-      for (int i = 0, q = 0; i < 4; i++)
-        if (i != c) cc[q++] = i;
-      const float mn = m[rr[0]][cc[0]] * (m[rr[1]][cc[1]] * m[rr[2]][cc[2]] - m[rr[1]][cc[2]] * m[rr[2]][cc[1]]) -
-                       m[rr[0]][cc[1]] * (m[rr[1]][cc[0]] * m[rr[2]][cc[2]] - m[rr[1]][cc[2]] * m[rr[2]][cc[0]]) +
-                       m[rr[0]][cc[2]] * (m[rr[1]][cc[0]] * m[rr[2]][cc[1]] - m[rr[1]][cc[1]] * m[rr[2]][cc[0]]);
-      cof[r][c] = ((r + c) & 1) ? -mn : mn;
-    }
+    inv[0][r] = (vec1[r] * fac0[r] - vec2[r] * fac1[r] + vec3[r] * fac2[r]) * sign_a[r];
+    inv[1][r] = (vec0[r] * fac0[r] - vec2[r] * fac3[r] + vec3[r] * fac4[r]) * sign_b[r];
+    inv[2][r] = (vec0[r] * fac1[r] - vec1[r] * fac3[r] + vec3[r] * fac5[r]) * sign_a[r];
+    inv[3][r] = (vec0[r] * fac2[r] - vec1[r] * fac4[r] + vec2[r] * fac5[r]) * sign_b[r];
   }
-  const float det = m[0][0] * cof[0][0] + m[0][1] * cof[0][1] + m[0][2] * cof[0][2] + m[0][3] * cof[0][3];
-  const float inv_det = 1.0f / det;
+  const float d0 = m[0][0] * inv[0][0], d1 = m[0][1] * inv[1][0], d2 = m[0][2] * inv[2][0], d3 = m[0][3] * inv[3][0];
+  const float one_over_det = 1.0f / ((d0 + d1) + (d2 + d3));
+  // transpose(inverse(M))[k] = row k of the inverse
   nova_triangle_data td;
-  td.x = { cof[0][0] * inv_det, cof[1][0] * inv_det, cof[2][0] * inv_det, cof[3][0] * inv_det };
-  td.y = { cof[0][1] * inv_det, cof[1][1] * inv_det, cof[2][1] * inv_det, cof[3][1] * inv_det };
-  td.z = { cof[0][2] * inv_det, cof[1][2] * inv_det, cof[2][2] * inv_det, cof[3][2] * inv_det };
+  td.x = { inv[0][0] * one_over_det, inv[1][0] * one_over_det, inv[2][0] * one_over_det, inv[3][0] * one_over_det };
+  td.y = { inv[0][1] * one_over_det, inv[1][1] * one_over_det, inv[2][1] * one_over_det, inv[3][1] * one_over_det };
+  td.z = { inv[0][2] * one_over_det, inv[1][2] * one_over_det, inv[2][2] * one_over_det, inv[3][2] * one_over_det };
   tris[p] = td;
 }
 

@@ -223,27 +223,42 @@ struct Builder {
   }
 };
 
-// General 4x4 inverse by cofactors (adjugate / determinant), single precision.
-void invert4(const float m[4][4], float inv[4][4]) {
-  auto minor3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
-    return m[r0][c0] * (m[r1][c1] * m[r2][c2] - m[r1][c2] * m[r2][c1]) -
-           m[r0][c1] * (m[r1][c0] * m[r2][c2] - m[r1][c2] * m[r2][c0]) +
-           m[r0][c2] * (m[r1][c0] * m[r2][c1] - m[r1][c1] * m[r2][c0]);
-  };
-  float cof[4][4];
+// glm::inverse(mat4) with glm's own operation order (include/glm/detail/func_matrix.inl:294-352, the
+// scalar path: mat4 is a packed type): m[c][r] is column c, row r.  No contraction (plain g++ -O2, no FMA).
+void glm_inverse(const float m[4][4], float inv[4][4]) {
+  const float c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+  const float c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+  const float c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+  const float c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+  const float c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+  const float c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+  const float c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+  const float c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+  const float c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  const float c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+  const float c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+  const float c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+  const float c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+  const float c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+  const float c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+  const float c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+  const float c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+  const float c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+  const float fac0[4] = { c00, c00, c02, c03 }, fac1[4] = { c04, c04, c06, c07 }, fac2[4] = { c08, c08, c10, c11 };
+  const float fac3[4] = { c12, c12, c14, c15 }, fac4[4] = { c16, c16, c18, c19 }, fac5[4] = { c20, c20, c22, c23 };
+  const float vec0[4] = { m[1][0], m[0][0], m[0][0], m[0][0] }, vec1[4] = { m[1][1], m[0][1], m[0][1], m[0][1] };
+  const float vec2[4] = { m[1][2], m[0][2], m[0][2], m[0][2] }, vec3[4] = { m[1][3], m[0][3], m[0][3], m[0][3] };
+  const float sign_a[4] = { 1.0f, -1.0f, 1.0f, -1.0f }, sign_b[4] = { -1.0f, 1.0f, -1.0f, 1.0f };
   for (int r = 0; r < 4; r++) {
-    for (int c = 0; c < 4; c++) {
-      int rr[3], cc[3];
-      for (int i = 0, k = 0; i < 4; i++) if (i != r) rr[k++] = i;
-      for (int i = 0, k = 0; i < 4; i++) if (i != c) cc[k++] = i;
-      float mn = minor3(rr[0], rr[1], rr[2], cc[0], cc[1], cc[2]);
-      cof[r][c] = ((r + c) & 1) ? -mn : mn;
-    }
+    inv[0][r] = (vec1[r] * fac0[r] - vec2[r] * fac1[r] + vec3[r] * fac2[r]) * sign_a[r];
+    inv[1][r] = (vec0[r] * fac0[r] - vec2[r] * fac3[r] + vec3[r] * fac4[r]) * sign_b[r];
+    inv[2][r] = (vec0[r] * fac1[r] - vec1[r] * fac3[r] + vec3[r] * fac5[r]) * sign_a[r];
+    inv[3][r] = (vec0[r] * fac2[r] - vec1[r] * fac4[r] + vec2[r] * fac5[r]) * sign_b[r];
   }
-  float det = m[0][0] * cof[0][0] + m[0][1] * cof[0][1] + m[0][2] * cof[0][2] + m[0][3] * cof[0][3];
-  float inv_det = 1.0f / det;
-  for (int r = 0; r < 4; r++)
-    for (int c = 0; c < 4; c++) inv[r][c] = cof[c][r] * inv_det;
+  const float d0 = m[0][0] * inv[0][0], d1 = m[0][1] * inv[1][0], d2 = m[0][2] * inv[2][0], d3 = m[0][3] * inv[3][0];
+  const float one_over_det = 1.0f / ((d0 + d1) + (d2 + d3));
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) inv[c][r] = inv[c][r] * one_over_det;
 }
 
 // intersectable_manager.cpp:8-42
@@ -393,17 +408,15 @@ void* nova_scene_build(const float* verts, const nova_triangle_meta* meta, const
     V3 e1 = t.v2 - t.v1, e2 = t.v3 - t.v1;
     V3 nrm = normalize(cross(e1, e2));
     V3 c2 = nrm - t.v1;
-    // column-major [e1 e2 n-v1 v1] with bottom row (0 0 0 1), as a row-major array
-    float m[4][4] = { { e1.x, e2.x, c2.x, t.v1.x },
-                      { e1.y, e2.y, c2.y, t.v1.y },
-                      { e1.z, e2.z, c2.z, t.v1.z },
-                      { 0.0f, 0.0f, 0.0f, 1.0f } };
+    // transform[0..3] = (e1,0) (e2,0) (n-v1,0) (v1,1): columns, m[c][r]
+    const float m[4][4] = { { e1.x, e1.y, e1.z, 0.0f }, { e2.x, e2.y, e2.z, 0.0f }, { c2.x, c2.y, c2.z, 0.0f },
+                            { t.v1.x, t.v1.y, t.v1.z, 1.0f } };
     float inv[4][4];
-    invert4(m, inv);
-    // glm: transform = transpose(inverse(M)); transform[k] (k-th column) = k-th row of inverse(M)
-    built->tris[i].x = { inv[0][0], inv[0][1], inv[0][2], inv[0][3] };
-    built->tris[i].y = { inv[1][0], inv[1][1], inv[1][2], inv[1][3] };
-    built->tris[i].z = { inv[2][0], inv[2][1], inv[2][2], inv[2][3] };
+    glm_inverse(m, inv);
+    // transpose(inverse(M))[k] = row k of the inverse = (inv[0][k], inv[1][k], inv[2][k], inv[3][k])
+    built->tris[i].x = { inv[0][0], inv[1][0], inv[2][0], inv[3][0] };
+    built->tris[i].y = { inv[0][1], inv[1][1], inv[2][1], inv[3][1] };
+    built->tris[i].z = { inv[0][2], inv[1][2], inv[2][2], inv[3][2] };
 
     nova_triangle_meta mm = metas[built->tri_order[i]];
     V3 e = ke[built->tri_order[i]];

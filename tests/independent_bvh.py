@@ -114,3 +114,56 @@ def build(verts):
     flat, order = [], []
     flatten(root, flat, order)
     return np.array(flat, np.float32), np.array(order, np.uint32)
+
+
+def glm_inverse(m):
+    """glm::inverse(mat4), scalar path, in its operation order (include/glm/detail/func_matrix.inl:294-352).
+    m[c][r] float32 (column c, row r) -> same layout."""
+    c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3]
+    c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3]
+    c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3]
+    c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3]
+    c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3]
+    c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3]
+    c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2]
+    c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2]
+    c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2]
+    c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3]
+    c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3]
+    c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3]
+    c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2]
+    c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2]
+    c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2]
+    c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1]
+    c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1]
+    c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1]
+    v4 = lambda *a: np.array(a, np.float32)  # noqa: E731
+    fac0, fac1, fac2 = v4(c00, c00, c02, c03), v4(c04, c04, c06, c07), v4(c08, c08, c10, c11)
+    fac3, fac4, fac5 = v4(c12, c12, c14, c15), v4(c16, c16, c18, c19), v4(c20, c20, c22, c23)
+    vec0, vec1 = v4(m[1][0], m[0][0], m[0][0], m[0][0]), v4(m[1][1], m[0][1], m[0][1], m[0][1])
+    vec2, vec3 = v4(m[1][2], m[0][2], m[0][2], m[0][2]), v4(m[1][3], m[0][3], m[0][3], m[0][3])
+    sign_a, sign_b = v4(1, -1, 1, -1), v4(-1, 1, -1, 1)
+    inverse = np.stack([(vec1 * fac0 - vec2 * fac1 + vec3 * fac2) * sign_a,
+                        (vec0 * fac0 - vec2 * fac3 + vec3 * fac4) * sign_b,
+                        (vec0 * fac1 - vec1 * fac3 + vec3 * fac5) * sign_a,
+                        (vec0 * fac2 - vec1 * fac4 + vec2 * fac5) * sign_b])
+    dot0 = m[0] * inverse[:, 0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        one_over_determinant = F(1.0) / F(F(dot0[0] + dot0[1]) + F(dot0[2] + dot0[3]))
+        return inverse * one_over_determinant
+
+
+def woop(tri):
+    """intersectable_manager.cpp:129-145 for one triangle (float32 [3, 3]) -> float32 [3, 4]."""
+    v1, v2, v3 = (np.asarray(t, np.float32) for t in tri)
+    e1, e2 = v2 - v1, v3 - v1
+    cross = np.array([e1[1] * e2[2] - e2[1] * e1[2], e1[2] * e2[0] - e2[2] * e1[0], e1[0] * e2[1] - e2[0] * e1[1]],
+                     np.float32)  # glm::cross
+    with np.errstate(divide="ignore", invalid="ignore"):
+        length2 = F(F(cross[0] * cross[0] + cross[1] * cross[1]) + cross[2] * cross[2])  # glm::dot
+        normal = cross * (F(1.0) / np.sqrt(length2))                                    # v * inversesqrt(dot(v, v))
+        m = np.zeros((4, 4), np.float32)
+        m[0, :3], m[1, :3], m[2, :3], m[3, :3] = e1, e2, normal - v1, v1
+        m[3, 3] = 1.0
+        inv = glm_inverse(m)
+    return inv.T[:3].copy()  # transpose(inverse)[k] = row k of the inverse

@@ -54,3 +54,15 @@ def test_the_reading_is_sensitive_to_what_it_checks():
     finally:
         B.MAX_BINS = saved
     assert len(other) != len(flat) or not np.array_equal(other, flat)
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup40", "knot", "clusters"])
+def test_woop_matrices_follow_glm_inverse_operation_order(name):
+    """TriangleData = rows 0..2 of transpose(glm::inverse([e1 e2 n-v1 v1])) (intersectable_manager.cpp:129-145):
+    the CPU builder's matrices against a numpy float32 reading of glm's scalar mat4 inverse, bit for bit."""
+    verts = np.ascontiguousarray(SCENES[name], np.float32).reshape(-1, 9)[:300]
+    sc = S.build_scene(verts)
+    got = sc.triangles.view(np.float32).reshape(-1, 3, 4)
+    for i, t in enumerate(sc.tri_order):
+        want = B.woop(verts[t].reshape(3, 3))
+        assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (i, got[i], want)
