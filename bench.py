@@ -176,6 +176,22 @@ def main():
     rays = rays_primary + rays_bounce + rays_shadow
     rays_local = int(local[0] + local[1] + local[2])
 
+    # Informational, outside the timed region: the same K samples through nova_hip_render_samples
+    # (one enqueue, one host wait, one post-process; byte-identical images, tests/test_gpu_render_samples.py).
+    fused = None
+    if world == 1:
+        rt.start()
+        rt.raytrace_samples([(SEED + i) & 0xFFFFFFFF for i in range(args.steps)], read_back=False)  # warm
+        rt.start()
+        capi.synchronize()
+        f0 = time.perf_counter()
+        rt.raytrace_samples([(SEED + i) & 0xFFFFFFFF for i in range(args.steps)], read_back=False)
+        capi.synchronize()
+        fdt = time.perf_counter() - f0
+        fused = {"entry": "nova_hip_render_samples", "samples": args.steps,
+                 "ms_per_sample": round(fdt / args.steps * 1e3, 4),
+                 "mrays_per_s": round(rays_local / fdt / 1e6, 2)}
+
     if rank == 0:
         out = {
             "metric": "Mrays/s (primary + incoherent bounce)",
@@ -245,6 +261,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["roofline"] = roof
+        if fused is not None:
+            out["fused_samples"] = fused
         if args.check_frame and frame is not None:
             # the gathered frame against this rank rendering every tile itself, same seeds
             capi.set_option(capi.OPT_TILE_RANK, 0)

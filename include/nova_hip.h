@@ -197,6 +197,41 @@ int nova_hip_launch_post_process(const nova_scene_params* params,
                                  uint32_t width, uint32_t height);
 
 /* ---------------------------------------------------------------------------------------------
+ * Several samples in one call.  Replaces num_samples consecutive calls of
+ * Raytracer::raytrace's device schedule (src/core/raytracer.cpp:169-262: kernel_raytrace,
+ * kernel_accumulate, copy_image2D of the running mean and features, kernel_post_process) — the
+ * reference waits for the device three times and copies one to three whole images per sample
+ * (:195-210, :244-255).  Here every kernel of every sample is enqueued at once and the host waits
+ * once; the running mean ping-pongs between prev_color and temp_color2 instead of being copied.
+ * Sample k (k = 0 .. num_samples-1) is seeded with times[k] and accumulated with sample index
+ * first_sample_index + k.  On return every image holds exactly the bytes the four-call schedule
+ * would have left: temp_color1 / *_feature1 = the last sample, temp_color2 == prev_color = the mean
+ * over all samples so far (likewise the features), pixels = kernel_post_process of that mean.
+ * The feature images may be NULL when denoise_available == 0.  The OIDN hand-off (:211-242) is
+ * not part of it: a caller that denoises does so on the final features.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nova_hip_frame_images {
+  nova_hip_image* temp_color1;
+  nova_hip_image* temp_color2;
+  nova_hip_image* prev_color;
+  nova_hip_image* albedo_feature1;
+  nova_hip_image* normal_feature1;
+  nova_hip_image* albedo_feature2;
+  nova_hip_image* normal_feature2;
+  nova_hip_image* prev_albedo_feature;
+  nova_hip_image* prev_normal_feature;
+  nova_hip_image* pixels; /* uchar4 */
+} nova_hip_frame_images;
+int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* times,
+                            uint32_t num_samples, int32_t first_sample_index,
+                            const nova_hip_frame_images* images, uint32_t width, uint32_t height,
+                            const nova_triangle_data* triangles,
+                            const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                            const nova_area_light* lights, uint32_t num_lights,
+                            const nova_hip_image* materials, const nova_hip_image* sky,
+                            uint32_t denoise_available);
+
+/* ---------------------------------------------------------------------------------------------
  * Ray batches.  find_intersection (kernels/raytrace.hpp:38-102) over an array of rays, for
  * callers that generate their own rays (BASELINE config 4: 16 M incoherent rays per batch).
  * Each ray is built as the reference builds it at every call site (raytrace.hpp:132,216,239):

@@ -6,6 +6,9 @@
 #ifndef HIP_ENTRY_HPP
 #define HIP_ENTRY_HPP
 
+#include <cstdint>
+#include <vector>
+
 #include "backend/hip/types/types.hpp"
 
 #if __has_include("kernel_types/scene_params.hpp")
@@ -63,6 +66,23 @@ inline void kernel_post_process(dim3, dim3, const SceneParams& scene_params, Ima
   HIP_CHECK_AND_THROW(nova_hip_launch_post_process(
     reinterpret_cast<const nova_scene_params*>(&scene_params), temp_color2, pixels, pixel_dims.x,
     pixel_dims.y));
+}
+
+// Extension (no kernel of this name in the reference): `times.size()` iterations of the body of
+// Raytracer::raytrace (src/core/raytracer.cpp:169-262, without the OIDN hand-off and the per-sample
+// read-back) as one device schedule with one host wait — include/nova_hip.h, nova_hip_render_samples.
+// A renderer adopts it by replacing its per-sample loop; the images end up byte-identical.
+inline void render_samples(const SceneParams& scene_params, const std::vector<uint32_t>& times,
+                           int first_sample_index, const nova_hip_frame_images& images, uint2 pixel_dims,
+                           TriangleData* triangles, TriangleMetaData* tri_meta, FlatBVHNode* bvh,
+                           AreaLightData* lights, uint num_lights, ImageHandle materials, ImageHandle sky,
+                           uint denoise_available) {
+  HIP_CHECK_AND_THROW(nova_hip_render_samples(
+    reinterpret_cast<const nova_scene_params*>(&scene_params), times.data(),
+    static_cast<uint32_t>(times.size()), first_sample_index, &images, pixel_dims.x, pixel_dims.y,
+    reinterpret_cast<const nova_triangle_data*>(triangles),
+    reinterpret_cast<const nova_triangle_meta*>(tri_meta), reinterpret_cast<const nova_bvh_node*>(bvh),
+    reinterpret_cast<const nova_area_light*>(lights), num_lights, materials, sky, denoise_available));
 }
 
 }

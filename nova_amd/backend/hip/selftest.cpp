@@ -4,6 +4,7 @@
 // to compare with the oracle.  Built by __graft_entry__.build() with plain g++ (no HIP headers):
 //   g++ -DBACKEND_HIP -I include -I nova_amd selftest.cpp -L nova_amd -lnova_hip
 // usage: selftest <dir> <width> <height> <samples> <seed> <denoise_available>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -169,6 +170,39 @@ int main(int argc, char** argv) {
     if (denoise_available) {
       dump(dir + "/out_albedo.bin", accelerator.read_image2D(albedo_img2, width, height));
       dump(dir + "/out_normal.bin", accelerator.read_image2D(normal_img2, width, height));
+    }
+
+    // ---- the same samples as one device schedule (nova::render_samples) ----------------------------
+    {
+      const auto color_ref = accelerator.read_image2D(temp_color_img2, width, height);
+      accelerator.fill_image2D(prev_color_img, width, height, float4 {});
+      std::vector<uint32_t> times;
+      for (int i = 0; i < samples; i++) times.push_back(seed + static_cast<uint32_t>(i));
+      nova_hip_frame_images images {};
+      images.temp_color1 = temp_color_img1.write_access().data();
+      images.temp_color2 = temp_color_img2.write_access().data();
+      images.prev_color = prev_color_img.data();
+      images.pixels = color_img.data();
+      if (denoise_available) {
+        images.albedo_feature1 = albedo_img1.write_access().data();
+        images.normal_feature1 = normal_img1.write_access().data();
+        images.albedo_feature2 = albedo_img2.write_access().data();
+        images.normal_feature2 = normal_img2.write_access().data();
+        images.prev_albedo_feature = prev_albedo_img.data();
+        images.prev_normal_feature = prev_normal_img.data();
+      }
+      render_samples(params[0], times, 0, images, uint2 { width, height }, triangle_buf.data(), tri_meta_buf.data(),
+                     bvh_buf.data(), light_buf.data(), static_cast<uint32_t>(light_data.size()), material_imgs.data(),
+                     sky_img.data(), denoise_available);
+      const auto fused_pixels = accelerator.read_image2D(color_img, width, height);
+      const auto fused_color = accelerator.read_image2D(temp_color_img2, width, height);
+      std::vector<float4> fused_prev(fused_color.size()); // an Image2DRead has no read-back in Nova's interface
+      HIP_CHECK_AND_THROW(nova_hip_image_read(prev_color_img.data(), fused_prev.data()));
+      if (std::memcmp(fused_pixels.data(), pixels.data(), pixels.size() * sizeof(uchar4)) != 0 ||
+          std::memcmp(fused_color.data(), color_ref.data(), color_ref.size() * sizeof(float4)) != 0 ||
+          std::memcmp(fused_prev.data(), color_ref.data(), color_ref.size() * sizeof(float4)) != 0)
+        throw std::runtime_error("render_samples differs from the per-sample schedule");
+      std::cout << "render_samples OK" << std::endl;
     }
 
     // a launch error must surface as nova::Error (cuda/accelerator/accelerator.hpp:28-29)

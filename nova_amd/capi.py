@@ -27,7 +27,7 @@ EXPORTS = [
     "nova_hip_image_create", "nova_hip_image_destroy", "nova_hip_image_read",
     "nova_hip_image_write", "nova_hip_image_copy", "nova_hip_image_fill",
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
-    "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
+    "nova_hip_render_samples", "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
 ]
@@ -100,6 +100,7 @@ def load() -> ctypes.CDLL:
         "nova_hip_launch_raytrace": [vp, u32, vp, u32, u32, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp],
         "nova_hip_launch_accumulate": [i32, u32] + [vp] * 9 + [u32, u32],
         "nova_hip_launch_post_process": [vp, vp, vp, u32, u32],
+        "nova_hip_render_samples": [vp, vp, u32, i32, vp, u32, u32, vp, vp, vp, vp, u32, vp, vp, u32],
         "nova_hip_trace_rays": [vp, vp, vp, vp, vp, u64],
         "nova_hip_set_option": [ctypes.c_int, i64],
         "nova_hip_get_option": [ctypes.c_int, vp],
@@ -287,6 +288,26 @@ def launch_post_process(params: np.ndarray, color2: Image, pixels: Image, width:
     params = np.ascontiguousarray(params)
     check(load().nova_hip_launch_post_process(params.ctypes.data, _h(color2), _h(pixels), width,
                                               height))
+
+
+class FrameImages(ctypes.Structure):
+    """nova_hip_frame_images (include/nova_hip.h): the images Raytracer keeps per frame."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "temp_color1", "temp_color2", "prev_color", "albedo_feature1", "normal_feature1",
+        "albedo_feature2", "normal_feature2", "prev_albedo_feature", "prev_normal_feature", "pixels")]
+
+
+def render_samples(params: np.ndarray, times, first_sample_index: int, images: FrameImages,
+                   width: int, height: int, triangles: Buffer, tri_meta: Buffer, bvh: Buffer,
+                   lights: Optional[Buffer], num_lights: int, materials: Image, sky: Image,
+                   denoise_available: int):
+    params = np.ascontiguousarray(params)
+    times = np.ascontiguousarray(np.asarray(times, np.uint64) & 0xFFFFFFFF, np.uint32)
+    check(load().nova_hip_render_samples(
+        params.ctypes.data, times.ctypes.data if times.size else None, times.size,
+        first_sample_index, ctypes.addressof(images), width, height, triangles.ptr, tri_meta.ptr,
+        bvh.ptr, None if lights is None else lights.ptr, num_lights, _h(materials), _h(sky),
+        denoise_available))
 
 
 def trace_rays(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Buffer, hits: Buffer,

@@ -957,13 +957,14 @@ int nova_hip_reset_counters(void) {
 }
 
 // ---- kernel_raytrace ---------------------------------------------------------------------------
-int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nova_hip_image* temp_color1,
-                             uint32_t width, uint32_t height, const nova_triangle_data* triangles,
-                             const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
-                             const nova_area_light* lights, uint32_t num_lights,
-                             const nova_hip_image* materials, const nova_hip_image* sky,
-                             uint32_t denoise_available, nova_hip_image* albedo_feature1,
-                             nova_hip_image* normal_feature1) {
+// `sync` = false: everything is left enqueued on the library's stream (nova_hip_render_samples).
+static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hip_image* temp_color1,
+                         uint32_t width, uint32_t height, const nova_triangle_data* triangles,
+                         const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                         const nova_area_light* lights, uint32_t num_lights,
+                         const nova_hip_image* materials, const nova_hip_image* sky,
+                         uint32_t denoise_available, nova_hip_image* albedo_feature1,
+                         nova_hip_image* normal_feature1, bool sync) {
   int rc = require_ctx();
   if (rc) return rc;
   if (!params || !triangles || !tri_meta || !bvh || width == 0 || height == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1076,6 +1077,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
       if (*g.h_pinned == 0) break;
     }
   }
+  if (!sync) return 0;
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
   if (std::getenv("NOVA_HIP_TRACE_QUEUES")) { // diagnostics: paths alive at the start of each iteration
@@ -1088,14 +1090,25 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   return 0;
 }
 
+int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nova_hip_image* temp_color1,
+                             uint32_t width, uint32_t height, const nova_triangle_data* triangles,
+                             const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                             const nova_area_light* lights, uint32_t num_lights,
+                             const nova_hip_image* materials, const nova_hip_image* sky,
+                             uint32_t denoise_available, nova_hip_image* albedo_feature1,
+                             nova_hip_image* normal_feature1) {
+  return raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
+                       materials, sky, denoise_available, albedo_feature1, normal_feature1, true);
+}
+
 // ---- kernel_accumulate -------------------------------------------------------------------------
-int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
-                               const nova_hip_image* temp_color1, const nova_hip_image* albedo_feature1,
-                               const nova_hip_image* normal_feature1, const nova_hip_image* prev_color,
-                               const nova_hip_image* prev_albedo_feature,
-                               const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
-                               nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
-                               uint32_t width, uint32_t height) {
+static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
+                           const nova_hip_image* temp_color1, const nova_hip_image* albedo_feature1,
+                           const nova_hip_image* normal_feature1, const nova_hip_image* prev_color,
+                           const nova_hip_image* prev_albedo_feature,
+                           const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
+                           nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
+                           uint32_t width, uint32_t height, bool sync) {
   int rc = require_ctx();
   if (rc) return rc;
   if (width == 0 || height == 0 || sample_index < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1124,10 +1137,23 @@ int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
   A.width = width;
   A.height = height;
   const unsigned blocks = std::min<unsigned>((width * height + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+  g.chain_tail = nullptr; // a later timing span must not start before this kernel
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, g.stream, A);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(g.stream));
+  if (sync) HIP_TRY(hipStreamSynchronize(g.stream));
   return 0;
+}
+
+int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
+                               const nova_hip_image* temp_color1, const nova_hip_image* albedo_feature1,
+                               const nova_hip_image* normal_feature1, const nova_hip_image* prev_color,
+                               const nova_hip_image* prev_albedo_feature,
+                               const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
+                               nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
+                               uint32_t width, uint32_t height) {
+  return accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
+                         prev_albedo_feature, prev_normal_feature, temp_color2, albedo_feature2, normal_feature2,
+                         width, height, true);
 }
 
 // ---- kernel_post_process -----------------------------------------------------------------------
@@ -1151,6 +1177,72 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g.stream));
   return 0;
+}
+
+// ---- several samples in one call ---------------------------------------------------------------
+// Raytracer::raytrace (src/core/raytracer.cpp:169-262) called num_samples times, without what only
+// the host needs between samples: every kernel of every sample is enqueued on the library's stream
+// and the host waits once, at the end.  prev / temp2 ping-pong by pointer (sample k reads the
+// plane sample k-1 wrote) and are made equal by one copy at the end instead of one per sample;
+// kernel_post_process runs once, on the final mean.  Same kernels, same order per pixel, so every
+// image ends with the bytes the four-call schedule leaves (tests/test_gpu_parity.py).
+int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* times, uint32_t num_samples,
+                            int32_t first_sample_index, const nova_hip_frame_images* images,
+                            uint32_t width, uint32_t height, const nova_triangle_data* triangles,
+                            const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
+                            const nova_area_light* lights, uint32_t num_lights,
+                            const nova_hip_image* materials, const nova_hip_image* sky,
+                            uint32_t denoise_available) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!params || !times || !images || num_samples == 0 || first_sample_index < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (static_cast<int64_t>(first_sample_index) + num_samples > INT32_MAX) return NOVA_HIP_E_TOO_LARGE;
+  const nova_hip_frame_images& I = *images;
+  if (!float_image_ok(I.temp_color1, width, height) || !float_image_ok(I.temp_color2, width, height) ||
+      !float_image_ok(I.prev_color, width, height))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!I.pixels || !I.pixels->data || I.pixels->texel_bytes != 4 || I.pixels->width != width || I.pixels->height != height)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (denoise_available) {
+    const nova_hip_image* need[] = { I.albedo_feature1, I.normal_feature1, I.albedo_feature2, I.normal_feature2,
+                                     I.prev_albedo_feature, I.prev_normal_feature };
+    for (const nova_hip_image* im : need)
+      if (!float_image_ok(im, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  }
+  // local descriptors whose data pointers swap; [0] = the "prev" role, [1] = the "temp2" role
+  nova_hip_image color[2] = { *I.prev_color, *I.temp_color2 };
+  nova_hip_image albedo[2], normal[2];
+  if (denoise_available) {
+    albedo[0] = *I.prev_albedo_feature; albedo[1] = *I.albedo_feature2;
+    normal[0] = *I.prev_normal_feature; normal[1] = *I.normal_feature2;
+  }
+  int in = 0;
+  for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
+    rc = raytrace_impl(params, times[k], I.temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
+                       materials, sky, denoise_available, I.albedo_feature1, I.normal_feature1, false);
+    if (rc) break;
+    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, I.temp_color1,
+                         I.albedo_feature1, I.normal_feature1, &color[in], denoise_available ? &albedo[in] : nullptr,
+                         denoise_available ? &normal[in] : nullptr, &color[in ^ 1],
+                         denoise_available ? &albedo[in ^ 1] : nullptr, denoise_available ? &normal[in ^ 1] : nullptr,
+                         width, height, false);
+    in ^= 1;
+  }
+  if (rc) {
+    (void) hipStreamSynchronize(g.stream);
+    collect_events();
+    return rc;
+  }
+  // color[in] holds the final mean; the other plane of the pair gets a copy (raytracer.cpp:202-210)
+  const size_t plane = static_cast<size_t>(width) * height * 16;
+  HIP_TRY(hipMemcpyAsync(color[in ^ 1].data, color[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
+  if (denoise_available) {
+    HIP_TRY(hipMemcpyAsync(albedo[in ^ 1].data, albedo[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(normal[in ^ 1].data, normal[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
+  }
+  rc = nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for the stream
+  collect_events();
+  return rc;
 }
 
 // ---- ray batches -------------------------------------------------------------------------------

@@ -98,6 +98,26 @@ class Raytracer:
         self.sample_index += 1
         return self.color_img.read() if read_back else None
 
+    def frame_images(self) -> capi.FrameImages:
+        h = lambda im: None if im is None else im.handle  # noqa: E731
+        return capi.FrameImages(
+            temp_color1=h(self.temp_color_img1), temp_color2=h(self.temp_color_img2),
+            prev_color=h(self.prev_color_img), albedo_feature1=h(self.albedo_img1),
+            normal_feature1=h(self.normal_img1), albedo_feature2=h(self.albedo_img2),
+            normal_feature2=h(self.normal_img2), prev_albedo_feature=h(self.prev_albedo_img),
+            prev_normal_feature=h(self.prev_normal_img), pixels=h(self.color_img))
+
+    def raytrace_samples(self, times, read_back: bool = True):
+        """len(times) calls of raytrace() as ONE device schedule (nova_hip_render_samples,
+        SURVEY.md §8f rank 2): same images afterwards, one host wait, one post-process."""
+        times = list(times)
+        capi.render_samples(self.params, times, self.sample_index, self.frame_images(), self.width,
+                            self.height, self.triangle_buf, self.tri_meta_buf, self.bvh_buf,
+                            self.light_buf, self.num_lights, self.material_imgs, self.sky_img,
+                            self.denoise_available)
+        self.sample_index += len(times)
+        return self.color_img.read() if read_back else None
+
     def step_time(self, seed: int) -> int:
         """Fixed-seed rule of the HIP backend: time = seed + sample_index (the reference seeds
         with wall-clock milliseconds, raytracer.cpp:175-176)."""
