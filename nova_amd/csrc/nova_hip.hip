@@ -88,6 +88,21 @@ struct FrameBuffers {
   uint32_t n_blocks = 0;
 };
 
+// What one sample in flight owns.  The context's own fields of these names are the CURRENT lane;
+// nova_hip_render_samples keeps a second one and swaps between samples (swap_lane), so that the
+// latency-bound tail of sample k (its last, nearly empty traversal launches) runs beside the start
+// of sample k+1 on another stream.
+struct Lane {
+  hipStream_t stream = nullptr;
+  FrameBuffers fb;
+  uint32_t* d_queues = nullptr;
+  uint32_t* d_heads = nullptr;
+  uint32_t* h_pinned = nullptr;
+  uint32_t* d_spill = nullptr;
+  size_t spill_words = 0;
+  hipEvent_t chain_tail = nullptr;
+};
+
 struct Ctx {
   bool ready = false;
   int device = -1;
@@ -115,6 +130,12 @@ struct Ctx {
   uint64_t traverse_launches = 0, camera_launches = 0;
   uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
   uint64_t folded[4] = { 0, 0, 0, 0 }; // block counters of released frame buffers
+  // second lane of nova_hip_render_samples (made on first use) and what orders the two lanes
+  Lane alt;
+  bool alt_ready = false;
+  hipEvent_t acc_done[2] = { nullptr, nullptr }; // recorded after kernel_accumulate of even / odd samples
+  float4* stage[3] = { nullptr, nullptr, nullptr }; // temp_color1 / albedo1 / normal1 of the other lane
+  size_t stage_bytes = 0;
 };
 
 Ctx g;
@@ -213,6 +234,39 @@ void collect_events() {
   g.ev_traverse.clear();
   g.ev_shade.clear();
   g.ev_used = 0;
+}
+
+void swap_lane() {
+  std::swap(g.stream, g.alt.stream);
+  std::swap(g.fb, g.alt.fb);
+  std::swap(g.d_queues, g.alt.d_queues);
+  std::swap(g.d_heads, g.alt.d_heads);
+  std::swap(g.h_pinned, g.alt.h_pinned);
+  std::swap(g.d_spill, g.alt.d_spill);
+  std::swap(g.spill_words, g.alt.spill_words);
+  std::swap(g.chain_tail, g.alt.chain_tail);
+}
+
+void free_frame_buffers(FrameBuffers& fb) {
+  for (int s = 0; s < 2; s++) {
+    for (int k = 0; k < 6; k++) { (void) hipFree(fb.planes[s][k]); fb.planes[s][k] = nullptr; }
+    (void) hipFree(fb.ray_o[s]); fb.ray_o[s] = nullptr;
+    (void) hipFree(fb.ray_d[s]); fb.ray_d[s] = nullptr;
+  }
+  (void) hipFree(fb.hits); fb.hits = nullptr;
+  (void) hipFree(fb.block_counters); fb.block_counters = nullptr;
+  fb.capacity = 0;
+  fb.n_blocks = 0;
+}
+
+// per-block ray counters of a lane's frame buffers, added to bc[4]
+int add_block_counters(const FrameBuffers& fb, uint64_t bc[4]) {
+  if (!fb.block_counters) return 0;
+  std::vector<unsigned long long> hb(4 * static_cast<size_t>(fb.n_blocks));
+  HIP_TRY(hipMemcpy(hb.data(), fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < fb.n_blocks; b++)
+    for (int q = 0; q < 4; q++) bc[q] += hb[4 * b + q];
+  return 0;
 }
 
 // ---- quad-per-ray layout (traverse_quad.hpp): both trees as child-major NodeQ arrays whose leaf
@@ -748,6 +802,18 @@ int nova_hip_shutdown(void) {
   (void) hipFree(g.fb.hits);
   g.fb.hits = nullptr;
   g.fb.capacity = 0;
+  if (g.alt_ready) {
+    (void) hipStreamSynchronize(g.alt.stream);
+    uint64_t bc[4] = { 0, 0, 0, 0 }; // its ray counts stay in the totals
+    if (add_block_counters(g.alt.fb, bc) == 0)
+      for (int q = 0; q < 4; q++) g.folded[q] += bc[q];
+    free_frame_buffers(g.alt.fb);
+    (void) hipFree(g.alt.d_spill);
+    g.alt.d_spill = nullptr;
+    g.alt.spill_words = 0;
+  }
+  for (auto& p : g.stage) { (void) hipFree(p); p = nullptr; }
+  g.stage_bytes = 0;
   return 0;
 }
 
@@ -922,12 +988,9 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost));
   uint64_t bc[4] = { g.folded[0], g.folded[1], g.folded[2], g.folded[3] };
-  if (g.fb.block_counters) {
-    std::vector<unsigned long long> hb(4 * static_cast<size_t>(g.fb.n_blocks));
-    HIP_TRY(hipMemcpy(hb.data(), g.fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < g.fb.n_blocks; b++)
-      for (int q = 0; q < 4; q++) bc[q] += hb[4 * b + q];
-  }
+  rc = add_block_counters(g.fb, bc);
+  if (rc == 0) rc = add_block_counters(g.alt.fb, bc);
+  if (rc) return rc;
   out->node_visits = h[0];
   out->triangle_tests = h[1];
   out->rays_primary = g.host_primary;
@@ -949,6 +1012,8 @@ int nova_hip_reset_counters(void) {
   collect_events();
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
   if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, 4 * static_cast<size_t>(g.fb.n_blocks) * 8));
+  if (g.alt.fb.block_counters)
+    HIP_TRY(hipMemset(g.alt.fb.block_counters, 0, 4 * static_cast<size_t>(g.alt.fb.n_blocks) * 8));
   for (auto& f : g.folded) f = 0;
   g.host_primary = 0;
   g.traverse_ms = g.camera_ms = g.shade_ms = 0;
@@ -1180,12 +1245,36 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
 }
 
 // ---- several samples in one call ---------------------------------------------------------------
+static int ensure_alt_lane(size_t plane_bytes, bool features) {
+  if (!g.alt_ready) {
+    HIP_TRY(hipStreamCreateWithFlags(&g.alt.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&g.alt.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t)));
+    g.alt.d_heads = g.alt.d_queues + kQueueWords;
+    HIP_TRY(hipHostMalloc(&g.alt.h_pinned, 64, hipHostMallocDefault));
+    for (auto& e : g.acc_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g.alt_ready = true;
+  }
+  if (plane_bytes > g.stage_bytes) {
+    for (auto& p : g.stage) { (void) hipFree(p); p = nullptr; }
+    g.stage_bytes = 0;
+  }
+  for (int k = 0; k < (features ? 3 : 1); k++)
+    if (!g.stage[k]) HIP_TRY(hipMalloc(&g.stage[k], std::max(plane_bytes, g.stage_bytes)));
+  g.stage_bytes = std::max(plane_bytes, g.stage_bytes);
+  return 0;
+}
+
 // Raytracer::raytrace (src/core/raytracer.cpp:169-262) called num_samples times, without what only
-// the host needs between samples: every kernel of every sample is enqueued on the library's stream
-// and the host waits once, at the end.  prev / temp2 ping-pong by pointer (sample k reads the
-// plane sample k-1 wrote) and are made equal by one copy at the end instead of one per sample;
-// kernel_post_process runs once, on the final mean.  Same kernels, same order per pixel, so every
-// image ends with the bytes the four-call schedule leaves (tests/test_gpu_parity.py).
+// the host needs between samples: every kernel of every sample is enqueued and the host waits once,
+// at the end.  prev / temp2 ping-pong by pointer (sample k reads the plane sample k-1 wrote) and are
+// made equal by one copy at the end instead of one per sample; kernel_post_process runs once, on the
+// final mean.  Consecutive samples run on two lanes (own stream, path state and ray queues each):
+// kernel_raytrace of sample k+1 does not depend on sample k, so it fills the GPU while sample k's
+// last traversal launches — a few thousand rays each, one latency chain per launch — drain.  Only
+// kernel_accumulate is ordered across lanes (an event per sample).  The lane that does not render
+// the last sample writes its radiance to a library-owned plane instead of temp_color1.
+// Same kernels, same order per pixel, so every image ends with the bytes the four-call schedule
+// leaves (tests/test_gpu_render_samples.py).  NOVA_HIP_NO_PIPELINE=1 keeps one lane (A/B).
 int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* times, uint32_t num_samples,
                             int32_t first_sample_index, const nova_hip_frame_images* images,
                             uint32_t width, uint32_t height, const nova_triangle_data* triangles,
@@ -1209,39 +1298,84 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
     for (const nova_hip_image* im : need)
       if (!float_image_ok(im, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
   }
+  const size_t plane = static_cast<size_t>(width) * height * 16;
+  static const bool no_pipeline = std::getenv("NOVA_HIP_NO_PIPELINE") != nullptr;
+  const bool two_lanes = num_samples >= 2 && !no_pipeline;
   // local descriptors whose data pointers swap; [0] = the "prev" role, [1] = the "temp2" role
   nova_hip_image color[2] = { *I.prev_color, *I.temp_color2 };
   nova_hip_image albedo[2], normal[2];
+  // radiance of one sample: [1] = the caller's images (the lane of the LAST sample), [0] = the library's
+  nova_hip_image one_color[2] = { *I.temp_color1, *I.temp_color1 };
+  nova_hip_image one_albedo[2], one_normal[2];
   if (denoise_available) {
     albedo[0] = *I.prev_albedo_feature; albedo[1] = *I.albedo_feature2;
     normal[0] = *I.prev_normal_feature; normal[1] = *I.normal_feature2;
+    one_albedo[0] = one_albedo[1] = *I.albedo_feature1;
+    one_normal[0] = one_normal[1] = *I.normal_feature1;
+  }
+  if (two_lanes) {
+    rc = ensure_alt_lane(plane, denoise_available != 0);
+    if (rc) return rc;
+    one_color[0].data = g.stage[0];
+    if (denoise_available) {
+      one_albedo[0].data = g.stage[1];
+      one_normal[0].data = g.stage[2];
+    }
+    if (g.opt_tile_ranks > 1) {
+      // kernel_raytrace leaves the pixels of other ranks' tiles as they are and kernel_accumulate reads
+      // them: the library's planes start as copies of the caller's, as if every sample had used those
+      HIP_TRY(hipMemcpyAsync(g.stage[0], I.temp_color1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+      if (denoise_available) {
+        HIP_TRY(hipMemcpyAsync(g.stage[1], I.albedo_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.stage[2], I.normal_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+      }
+      HIP_TRY(hipStreamSynchronize(g.stream)); // the other lane's first sample may write them at once
+    }
   }
   int in = 0;
+  uint32_t swaps = 0;
   for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
-    rc = raytrace_impl(params, times[k], I.temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
-                       materials, sky, denoise_available, I.albedo_feature1, I.normal_feature1, false);
+    const int own = (!two_lanes || ((num_samples - 1 - k) & 1u) == 0) ? 1 : 0;
+    rc = raytrace_impl(params, times[k], &one_color[own], width, height, triangles, tri_meta, bvh, lights, num_lights,
+                       materials, sky, denoise_available, denoise_available ? &one_albedo[own] : nullptr,
+                       denoise_available ? &one_normal[own] : nullptr, false);
     if (rc) break;
-    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, I.temp_color1,
-                         I.albedo_feature1, I.normal_feature1, &color[in], denoise_available ? &albedo[in] : nullptr,
+    if (two_lanes && k > 0) { // the running mean comes from the other lane's kernel_accumulate
+      hipError_t e = hipStreamWaitEvent(g.stream, g.acc_done[(k - 1) & 1u], 0);
+      if (e != hipSuccess) { rc = static_cast<int>(e); break; }
+    }
+    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, &one_color[own],
+                         denoise_available ? &one_albedo[own] : nullptr, denoise_available ? &one_normal[own] : nullptr,
+                         &color[in], denoise_available ? &albedo[in] : nullptr,
                          denoise_available ? &normal[in] : nullptr, &color[in ^ 1],
                          denoise_available ? &albedo[in ^ 1] : nullptr, denoise_available ? &normal[in ^ 1] : nullptr,
                          width, height, false);
+    if (rc) break;
     in ^= 1;
+    if (two_lanes && k + 1 < num_samples) {
+      hipError_t e = hipEventRecord(g.acc_done[k & 1u], g.stream);
+      if (e != hipSuccess) { rc = static_cast<int>(e); break; }
+      swap_lane();
+      swaps++;
+    }
   }
   if (rc) {
     (void) hipStreamSynchronize(g.stream);
+    if (g.alt_ready) (void) hipStreamSynchronize(g.alt.stream);
     collect_events();
     return rc;
   }
-  // color[in] holds the final mean; the other plane of the pair gets a copy (raytracer.cpp:202-210)
-  const size_t plane = static_cast<size_t>(width) * height * 16;
+  // the current lane holds the last sample; color[in] the final mean, whose pair plane gets a copy
+  // (raytracer.cpp:202-210)
   HIP_TRY(hipMemcpyAsync(color[in ^ 1].data, color[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
   if (denoise_available) {
     HIP_TRY(hipMemcpyAsync(albedo[in ^ 1].data, albedo[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(normal[in ^ 1].data, normal[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
   }
-  rc = nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for the stream
+  rc = nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for this lane
+  if (two_lanes) (void) hipStreamSynchronize(g.alt.stream); // done already: its last kernel was waited for above
   collect_events();
+  (void) swaps;
   return rc;
 }
 
