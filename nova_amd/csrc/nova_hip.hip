@@ -89,9 +89,11 @@ struct FrameBuffers {
 };
 
 // What one sample in flight owns.  The context's own fields of these names are the CURRENT lane;
-// nova_hip_render_samples keeps a second one and swaps between samples (swap_lane), so that the
+// nova_hip_render_samples keeps further ones and moves on between samples (switch_lane), so that the
 // latency-bound tail of sample k (its last, nearly empty traversal launches) runs beside the start
 // of sample k+1 on another stream.
+constexpr int kMaxLanes = 4;
+constexpr int kDefaultLanes = 3; // 1080p, 16 samples: 3.94 / 3.40 / 3.27 / 3.42 ms per sample with 1 / 2 / 3 / 4 lanes
 struct Lane {
   hipStream_t stream = nullptr;
   FrameBuffers fb;
@@ -130,11 +132,13 @@ struct Ctx {
   uint64_t traverse_launches = 0, camera_launches = 0;
   uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
   uint64_t folded[4] = { 0, 0, 0, 0 }; // block counters of released frame buffers
-  // second lane of nova_hip_render_samples (made on first use) and what orders the two lanes
-  Lane alt;
-  bool alt_ready = false;
+  // further lanes of nova_hip_render_samples (made on first use) and what orders the lanes.
+  // lanes[cur] is stale: the current lane lives in the fields above (switch_lane).
+  Lane lanes[kMaxLanes];
+  int cur = 0;
+  int lanes_ready = 1;
   hipEvent_t acc_done[2] = { nullptr, nullptr }; // recorded after kernel_accumulate of even / odd samples
-  float4* stage[3] = { nullptr, nullptr, nullptr }; // temp_color1 / albedo1 / normal1 of the other lane
+  float4* stage[kMaxLanes - 1][3] = {}; // temp_color1 / albedo1 / normal1 of the lanes that do not render the last sample
   size_t stage_bytes = 0;
 };
 
@@ -236,15 +240,15 @@ void collect_events() {
   g.ev_used = 0;
 }
 
-void swap_lane() {
-  std::swap(g.stream, g.alt.stream);
-  std::swap(g.fb, g.alt.fb);
-  std::swap(g.d_queues, g.alt.d_queues);
-  std::swap(g.d_heads, g.alt.d_heads);
-  std::swap(g.h_pinned, g.alt.h_pinned);
-  std::swap(g.d_spill, g.alt.d_spill);
-  std::swap(g.spill_words, g.alt.spill_words);
-  std::swap(g.chain_tail, g.alt.chain_tail);
+void switch_lane(int to) {
+  if (to == g.cur) return;
+  Lane& o = g.lanes[g.cur];
+  o.stream = g.stream; o.fb = g.fb; o.d_queues = g.d_queues; o.d_heads = g.d_heads; o.h_pinned = g.h_pinned;
+  o.d_spill = g.d_spill; o.spill_words = g.spill_words; o.chain_tail = g.chain_tail;
+  const Lane& n = g.lanes[to];
+  g.stream = n.stream; g.fb = n.fb; g.d_queues = n.d_queues; g.d_heads = n.d_heads; g.h_pinned = n.h_pinned;
+  g.d_spill = n.d_spill; g.spill_words = n.spill_words; g.chain_tail = n.chain_tail;
+  g.cur = to;
 }
 
 void free_frame_buffers(FrameBuffers& fb) {
@@ -802,17 +806,20 @@ int nova_hip_shutdown(void) {
   (void) hipFree(g.fb.hits);
   g.fb.hits = nullptr;
   g.fb.capacity = 0;
-  if (g.alt_ready) {
-    (void) hipStreamSynchronize(g.alt.stream);
+  for (int l = 0; l < g.lanes_ready; l++) {
+    if (l == g.cur) continue;
+    Lane& o = g.lanes[l];
+    (void) hipStreamSynchronize(o.stream);
     uint64_t bc[4] = { 0, 0, 0, 0 }; // its ray counts stay in the totals
-    if (add_block_counters(g.alt.fb, bc) == 0)
+    if (add_block_counters(o.fb, bc) == 0)
       for (int q = 0; q < 4; q++) g.folded[q] += bc[q];
-    free_frame_buffers(g.alt.fb);
-    (void) hipFree(g.alt.d_spill);
-    g.alt.d_spill = nullptr;
-    g.alt.spill_words = 0;
+    free_frame_buffers(o.fb);
+    (void) hipFree(o.d_spill);
+    o.d_spill = nullptr;
+    o.spill_words = 0;
   }
-  for (auto& p : g.stage) { (void) hipFree(p); p = nullptr; }
+  for (auto& lane : g.stage)
+    for (auto& p : lane) { (void) hipFree(p); p = nullptr; }
   g.stage_bytes = 0;
   return 0;
 }
@@ -989,7 +996,8 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   HIP_TRY(hipMemcpy(h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost));
   uint64_t bc[4] = { g.folded[0], g.folded[1], g.folded[2], g.folded[3] };
   rc = add_block_counters(g.fb, bc);
-  if (rc == 0) rc = add_block_counters(g.alt.fb, bc);
+  for (int l = 0; l < g.lanes_ready && rc == 0; l++)
+    if (l != g.cur) rc = add_block_counters(g.lanes[l].fb, bc);
   if (rc) return rc;
   out->node_visits = h[0];
   out->triangle_tests = h[1];
@@ -1012,8 +1020,9 @@ int nova_hip_reset_counters(void) {
   collect_events();
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
   if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, 4 * static_cast<size_t>(g.fb.n_blocks) * 8));
-  if (g.alt.fb.block_counters)
-    HIP_TRY(hipMemset(g.alt.fb.block_counters, 0, 4 * static_cast<size_t>(g.alt.fb.n_blocks) * 8));
+  for (int l = 0; l < g.lanes_ready; l++)
+    if (l != g.cur && g.lanes[l].fb.block_counters)
+      HIP_TRY(hipMemset(g.lanes[l].fb.block_counters, 0, 4 * static_cast<size_t>(g.lanes[l].fb.n_blocks) * 8));
   for (auto& f : g.folded) f = 0;
   g.host_primary = 0;
   g.traverse_ms = g.camera_ms = g.shade_ms = 0;
@@ -1245,22 +1254,26 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
 }
 
 // ---- several samples in one call ---------------------------------------------------------------
-static int ensure_alt_lane(size_t plane_bytes, bool features) {
-  if (!g.alt_ready) {
-    HIP_TRY(hipStreamCreateWithFlags(&g.alt.stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&g.alt.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t)));
-    g.alt.d_heads = g.alt.d_queues + kQueueWords;
-    HIP_TRY(hipHostMalloc(&g.alt.h_pinned, 64, hipHostMallocDefault));
+static int ensure_lanes(int lanes, size_t plane_bytes, bool features) {
+  if (!g.acc_done[0])
     for (auto& e : g.acc_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    g.alt_ready = true;
+  while (g.lanes_ready < lanes) { // lane numbers are handed out in order; the current one may be any of them
+    Lane& o = g.lanes[g.lanes_ready];
+    o = Lane {};
+    HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&o.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t)));
+    o.d_heads = o.d_queues + kQueueWords;
+    HIP_TRY(hipHostMalloc(&o.h_pinned, 64, hipHostMallocDefault));
+    g.lanes_ready++;
   }
   if (plane_bytes > g.stage_bytes) {
-    for (auto& p : g.stage) { (void) hipFree(p); p = nullptr; }
-    g.stage_bytes = 0;
+    for (auto& lane : g.stage)
+      for (auto& p : lane) { (void) hipFree(p); p = nullptr; }
+    g.stage_bytes = plane_bytes;
   }
-  for (int k = 0; k < (features ? 3 : 1); k++)
-    if (!g.stage[k]) HIP_TRY(hipMalloc(&g.stage[k], std::max(plane_bytes, g.stage_bytes)));
-  g.stage_bytes = std::max(plane_bytes, g.stage_bytes);
+  for (int l = 0; l + 1 < lanes; l++)
+    for (int k = 0; k < (features ? 3 : 1); k++)
+      if (!g.stage[l][k]) HIP_TRY(hipMalloc(&g.stage[l][k], g.stage_bytes));
   return 0;
 }
 
@@ -1274,7 +1287,7 @@ static int ensure_alt_lane(size_t plane_bytes, bool features) {
 // kernel_accumulate is ordered across lanes (an event per sample).  The lane that does not render
 // the last sample writes its radiance to a library-owned plane instead of temp_color1.
 // Same kernels, same order per pixel, so every image ends with the bytes the four-call schedule
-// leaves (tests/test_gpu_render_samples.py).  NOVA_HIP_NO_PIPELINE=1 keeps one lane (A/B).
+// leaves (tests/test_gpu_render_samples.py).  NOVA_HIP_LANES=1 keeps one lane (A/B).
 int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* times, uint32_t num_samples,
                             int32_t first_sample_index, const nova_hip_frame_images* images,
                             uint32_t width, uint32_t height, const nova_triangle_data* triangles,
@@ -1299,83 +1312,94 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
       if (!float_image_ok(im, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
   }
   const size_t plane = static_cast<size_t>(width) * height * 16;
-  static const bool no_pipeline = std::getenv("NOVA_HIP_NO_PIPELINE") != nullptr;
-  const bool two_lanes = num_samples >= 2 && !no_pipeline;
+  // lanes: NOVA_HIP_LANES=1..4 (A/B); default below
+  static const int env_lanes = [] {
+    const char* e = std::getenv("NOVA_HIP_LANES");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= kMaxLanes ? v : kDefaultLanes;
+  }();
+  const uint32_t L = std::min<uint32_t>(static_cast<uint32_t>(env_lanes), num_samples);
   // local descriptors whose data pointers swap; [0] = the "prev" role, [1] = the "temp2" role
   nova_hip_image color[2] = { *I.prev_color, *I.temp_color2 };
   nova_hip_image albedo[2], normal[2];
-  // radiance of one sample: [1] = the caller's images (the lane of the LAST sample), [0] = the library's
-  nova_hip_image one_color[2] = { *I.temp_color1, *I.temp_color1 };
-  nova_hip_image one_albedo[2], one_normal[2];
+  // radiance of one sample: [0] = the caller's images (the lane of the LAST sample), [r] = the library's
+  // planes of the lane that is r samples short of it
+  nova_hip_image one_color[kMaxLanes], one_albedo[kMaxLanes], one_normal[kMaxLanes];
+  for (auto& d : one_color) d = *I.temp_color1;
   if (denoise_available) {
     albedo[0] = *I.prev_albedo_feature; albedo[1] = *I.albedo_feature2;
     normal[0] = *I.prev_normal_feature; normal[1] = *I.normal_feature2;
-    one_albedo[0] = one_albedo[1] = *I.albedo_feature1;
-    one_normal[0] = one_normal[1] = *I.normal_feature1;
+    for (auto& d : one_albedo) d = *I.albedo_feature1;
+    for (auto& d : one_normal) d = *I.normal_feature1;
   }
-  if (two_lanes) {
-    rc = ensure_alt_lane(plane, denoise_available != 0);
+  if (L > 1) {
+    rc = ensure_lanes(static_cast<int>(L), plane, denoise_available != 0);
     if (rc) return rc;
-    one_color[0].data = g.stage[0];
-    if (denoise_available) {
-      one_albedo[0].data = g.stage[1];
-      one_normal[0].data = g.stage[2];
-    }
-    if (g.opt_tile_ranks > 1) {
-      // kernel_raytrace leaves the pixels of other ranks' tiles as they are and kernel_accumulate reads
-      // them: the library's planes start as copies of the caller's, as if every sample had used those
-      HIP_TRY(hipMemcpyAsync(g.stage[0], I.temp_color1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+    if (g.cur >= static_cast<int>(L)) switch_lane(0); // lanes 0..L-1 in turn: one plane set per lane
+    for (uint32_t r = 1; r < L; r++) {
+      one_color[r].data = g.stage[r - 1][0];
       if (denoise_available) {
-        HIP_TRY(hipMemcpyAsync(g.stage[1], I.albedo_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(g.stage[2], I.normal_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+        one_albedo[r].data = g.stage[r - 1][1];
+        one_normal[r].data = g.stage[r - 1][2];
       }
-      HIP_TRY(hipStreamSynchronize(g.stream)); // the other lane's first sample may write them at once
+      if (g.opt_tile_ranks > 1) {
+        // kernel_raytrace leaves the pixels of other ranks' tiles as they are and kernel_accumulate reads
+        // them: the library's planes start as copies of the caller's, as if every sample had used those
+        HIP_TRY(hipMemcpyAsync(one_color[r].data, I.temp_color1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+        if (denoise_available) {
+          HIP_TRY(hipMemcpyAsync(one_albedo[r].data, I.albedo_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+          HIP_TRY(hipMemcpyAsync(one_normal[r].data, I.normal_feature1->data, plane, hipMemcpyDeviceToDevice, g.stream));
+        }
+      }
     }
+    if (g.opt_tile_ranks > 1) HIP_TRY(hipStreamSynchronize(g.stream)); // other lanes may write them at once
   }
+  auto wait_all = [&]() {
+    (void) hipStreamSynchronize(g.stream);
+    for (int l = 0; l < g.lanes_ready; l++)
+      if (l != g.cur) (void) hipStreamSynchronize(g.lanes[l].stream);
+  };
   int in = 0;
-  uint32_t swaps = 0;
   for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
-    const int own = (!two_lanes || ((num_samples - 1 - k) & 1u) == 0) ? 1 : 0;
-    rc = raytrace_impl(params, times[k], &one_color[own], width, height, triangles, tri_meta, bvh, lights, num_lights,
-                       materials, sky, denoise_available, denoise_available ? &one_albedo[own] : nullptr,
-                       denoise_available ? &one_normal[own] : nullptr, false);
+    const uint32_t r = (num_samples - 1 - k) % L; // the same for every sample of a lane
+    nova_hip_image* c1 = &one_color[r];
+    nova_hip_image* a1 = denoise_available ? &one_albedo[r] : nullptr;
+    nova_hip_image* n1 = denoise_available ? &one_normal[r] : nullptr;
+    rc = raytrace_impl(params, times[k], c1, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
+                       denoise_available, a1, n1, false);
     if (rc) break;
-    if (two_lanes && k > 0) { // the running mean comes from the other lane's kernel_accumulate
+    if (L > 1 && k > 0) { // the running mean comes from the previous lane's kernel_accumulate
       hipError_t e = hipStreamWaitEvent(g.stream, g.acc_done[(k - 1) & 1u], 0);
       if (e != hipSuccess) { rc = static_cast<int>(e); break; }
     }
-    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, &one_color[own],
-                         denoise_available ? &one_albedo[own] : nullptr, denoise_available ? &one_normal[own] : nullptr,
-                         &color[in], denoise_available ? &albedo[in] : nullptr,
-                         denoise_available ? &normal[in] : nullptr, &color[in ^ 1],
-                         denoise_available ? &albedo[in ^ 1] : nullptr, denoise_available ? &normal[in ^ 1] : nullptr,
-                         width, height, false);
+    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, c1, a1, n1, &color[in],
+                         denoise_available ? &albedo[in] : nullptr, denoise_available ? &normal[in] : nullptr,
+                         &color[in ^ 1], denoise_available ? &albedo[in ^ 1] : nullptr,
+                         denoise_available ? &normal[in ^ 1] : nullptr, width, height, false);
     if (rc) break;
     in ^= 1;
-    if (two_lanes && k + 1 < num_samples) {
+    if (L > 1 && k + 1 < num_samples) {
       hipError_t e = hipEventRecord(g.acc_done[k & 1u], g.stream);
       if (e != hipSuccess) { rc = static_cast<int>(e); break; }
-      swap_lane();
-      swaps++;
+      switch_lane((g.cur + 1) % static_cast<int>(L));
     }
   }
   if (rc) {
-    (void) hipStreamSynchronize(g.stream);
-    if (g.alt_ready) (void) hipStreamSynchronize(g.alt.stream);
+    wait_all();
     collect_events();
     return rc;
   }
   // the current lane holds the last sample; color[in] the final mean, whose pair plane gets a copy
   // (raytracer.cpp:202-210)
-  HIP_TRY(hipMemcpyAsync(color[in ^ 1].data, color[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
-  if (denoise_available) {
-    HIP_TRY(hipMemcpyAsync(albedo[in ^ 1].data, albedo[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(normal[in ^ 1].data, normal[in].data, plane, hipMemcpyDeviceToDevice, g.stream));
+  hipError_t e = hipMemcpyAsync(color[in ^ 1].data, color[in].data, plane, hipMemcpyDeviceToDevice, g.stream);
+  if (e == hipSuccess && denoise_available) {
+    e = hipMemcpyAsync(albedo[in ^ 1].data, albedo[in].data, plane, hipMemcpyDeviceToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(normal[in ^ 1].data, normal[in].data, plane, hipMemcpyDeviceToDevice, g.stream);
   }
-  rc = nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for this lane
-  if (two_lanes) (void) hipStreamSynchronize(g.alt.stream); // done already: its last kernel was waited for above
+  rc = e != hipSuccess ? static_cast<int>(e)
+                       : nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for this lane
+  wait_all(); // the other lanes are done already: their last kernels were waited for by this one's
   collect_events();
-  (void) swaps;
   return rc;
 }
 

@@ -89,6 +89,44 @@ def test_fused_samples_continue_a_running_mean(cornell):
         assert same_bytes(ia[name], ib[name]), name
 
 
+def test_fused_calls_of_different_lengths_in_a_row(knot_small):
+    """The library rotates consecutive samples over its lanes (own stream and path state each) and the
+    number of lanes in use follows the call's length: 3, 2, 1, 4 and 7 samples on one frame == 17."""
+    w, h = 192, 128
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), path_tracing=True)
+    capi.set_option(capi.OPT_MAX_DEPTH, 5)
+    a = make(knot_small, p, w, h, True)
+    for k in range(17):
+        a.raytrace(50 + k)
+    b = make(knot_small, p, w, h, True)
+    k = 0
+    for n in (3, 2, 1, 4, 7):
+        b.raytrace_samples([50 + k + i for i in range(n)])
+        k += n
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    ia, ib = images_of(a), images_of(b)
+    for name in ia:
+        assert same_bytes(ia[name], ib[name]), name
+
+
+def test_fused_samples_keep_the_ray_counters(knot_small):
+    w, h = 192, 128
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), path_tracing=True)
+    capi.set_option(capi.OPT_MAX_DEPTH, 5)
+    a = make(knot_small, p, w, h, False)
+    capi.reset_counters()
+    for k in range(5):
+        a.raytrace(9 + k)
+    ka = capi.counters()
+    capi.reset_counters()
+    a.start()
+    a.raytrace_samples([9 + k for k in range(5)])
+    kb = capi.counters()
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    for name in ("rays_primary", "rays_bounce", "rays_shadow", "path_segments", "traverse_launches"):
+        assert ka[name] == kb[name], name
+
+
 def test_fused_samples_against_the_oracle(cornell):
     from oracle import bind as O
     w = h = 64
@@ -117,8 +155,15 @@ def test_fused_samples_under_a_tile_partition(knot_small):
     capi.set_option(capi.OPT_TILE_RANKS, 3)
     capi.set_option(capi.OPT_TILE_RANK, 1)
     part = make(knot_small, p, w, h, False)
-    part.temp_color_img1.fill([0.0] * 4)
-    part.raytrace_samples([11, 12, 13])
+    part.temp_color_img1.fill([0.25, 0.5, 0.75, 1.0])  # what other ranks' pixels hold is the caller's business,
+    part.raytrace_samples([11, 12, 13])                # but it must come out as the four-call schedule leaves it
+    calls = make(knot_small, p, w, h, False)
+    calls.temp_color_img1.fill([0.25, 0.5, 0.75, 1.0])
+    for t in (11, 12, 13):
+        calls.raytrace(t)
+    ip, ic = images_of(part), images_of(calls)
+    for name in ip:
+        assert same_bytes(ip[name], ic[name]), name
     capi.set_option(capi.OPT_TILE_RANK, 0)
     capi.set_option(capi.OPT_TILE_RANKS, 1)
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
