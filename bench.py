@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--grid", type=int, default=660, help="stand-in mesh resolution (2*grid^2 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="skip the informational nova_hip_render_samples run after the timed region "
+                         "(rocprofv3 --stats then averages the timed schedule's launches only)")
     ap.add_argument("--check-frame", action="store_true",
                     help="N > 1: rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
@@ -179,7 +182,7 @@ def main():
     # Informational, outside the timed region: the same K samples through nova_hip_render_samples
     # (one enqueue, one host wait, one post-process; byte-identical images, tests/test_gpu_render_samples.py).
     fused = None
-    if world == 1:
+    if world == 1 and not args.no_fused:
         rt.start()
         rt.raytrace_samples([(SEED + i) & 0xFFFFFFFF for i in range(args.steps)], read_back=False)  # warm
         rt.start()
