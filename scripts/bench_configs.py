@@ -30,6 +30,20 @@ def frames(rt, n, depth, label):
     rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"]) / n
     print("%s: %.2f ms/frame, %.2f Mrays/frame -> %.0f Mrays/s (traverse %.2f ms, shade %.2f ms per frame)" % (
         label, dt * 1e3, rays / 1e6, rays / dt / 1e6, c["traverse_ms"] / n, c["shade_ms"] / n), flush=True)
+    # the same frames through nova_hip_render_samples: n samples per call
+    m = max(n, 6)
+    rt.start()
+    rt.raytrace_samples([2 + i for i in range(m)], read_back=False)
+    rt.start()
+    capi.reset_counters()
+    capi.synchronize()
+    t = time.perf_counter()
+    rt.raytrace_samples([2 + i for i in range(m)], read_back=False)
+    capi.synchronize()
+    fdt = (time.perf_counter() - t) / m
+    c = capi.counters()
+    frays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"]) / m
+    print("%s, %d samples per call: %.2f ms/sample -> %.0f Mrays/s" % (label, m, fdt * 1e3, frays / fdt / 1e6), flush=True)
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
 
 

@@ -64,7 +64,7 @@ for c in range(n_cfg):
                             exposure=float(rng.uniform(0.3, 3.0)))
     depth = int(rng.choice([0, 1, 2, 3, 5, 8]))
     denoise = int(rng.uniform() < 0.5)
-    samples = int(rng.integers(1, 4))
+    samples = int(rng.integers(1, 6))
     seed = int(rng.integers(1, 2**31))
     rt = Raytracer(0, denoise_available=bool(denoise))
     rt.set_scene(sc, p, w, h)
@@ -86,6 +86,23 @@ for c in range(n_cfg):
             ok &= bool((rt.albedo_img2.read().view(np.uint32) == acc[1].view(np.uint32)).all())
             ok &= bool((rt.normal_img2.read().view(np.uint32) == acc[2].view(np.uint32)).all())
         ok &= bool((pixels == O.kernel_post_process(p, acc[0])).all())
+    # the same samples as ONE call (nova_hip_render_samples: lanes, ping-pong planes, one post-process)
+    last1 = ref
+    rt.start()
+    if denoise:
+        rt.prev_albedo_img.fill([0.0] * 4)
+        rt.prev_normal_img.fill([0.0] * 4)
+    pixels = rt.raytrace_samples([seed + s for s in range(samples)])
+    ok_f = bool((pixels == O.kernel_post_process(p, prev[0])).all())
+    pairs = [(rt.temp_color_img1, last1[0]), (rt.temp_color_img2, prev[0]), (rt.prev_color_img, prev[0])]
+    if denoise:
+        pairs += [(rt.albedo_img1, last1[1]), (rt.normal_img1, last1[2]), (rt.albedo_img2, prev[1]), (rt.normal_img2, prev[2]),
+                  (rt.prev_albedo_img, prev[1]), (rt.prev_normal_img, prev[2])]
+    for img, r in pairs:
+        ok_f &= bool((img.read().view(np.uint32) == r.view(np.uint32)).all())
+    if not ok_f:
+        print("  (the fused call differs)", flush=True)
+    ok &= ok_f
     # the same frame as tiles of 3 ranks, sample 0
     whole = None
     if pt:
