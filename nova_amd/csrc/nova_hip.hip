@@ -1031,14 +1031,82 @@ int nova_hip_reset_counters(void) {
 }
 
 // ---- kernel_raytrace ---------------------------------------------------------------------------
-// `sync` = false: everything is left enqueued on the library's stream (nova_hip_render_samples).
+// One path segment for every live path of the current lane: traverse the rays iteration `it` reads,
+// then shade (resolve segment it-1's direct light, shade segment it, emit the next rays).
+static int enqueue_iteration(const PackedScene& scene, const FrameArgs& F, uint32_t P, uint32_t it, bool nee) {
+  const int in = it & 1, out = in ^ 1;
+  TraverseArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.ray_o = g.fb.ray_o[in];
+  T.ray_d = g.fb.ray_d[in];
+  T.hits = g.fb.hits;
+  T.n_items_ptr = g.d_queues + it;
+  T.kinds = (nee && it > 0) ? 3u : 1u;
+  T.stride = P;
+  T.queue_head = g.d_heads + kHeadWords * it;
+  int rc = launch_traverse(scene, T, it == 0);
+  if (rc) return rc;
+  const unsigned shade_blocks = (P + kShadeBlock - 1) / kShadeBlock;
+  hipEvent_t e0 = nullptr;
+  span_begin(&e0);
+  hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(kShadeBlock), 0, g.stream, F, it, planes_of(in), planes_of(out),
+                     g.fb.ray_o[in], g.fb.ray_d[in], g.fb.hits, g.fb.ray_o[out], g.fb.ray_d[out]);
+  hipEvent_t e1 = span_end();
+  if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
+  return static_cast<int>(hipGetLastError());
+}
+
+// A sample of nova_hip_render_samples whose first iterations are enqueued on its lane.  With unbounded
+// paths (max_depth 0) only iterations 0..kSpeculativeLast are enqueued at once; whether any path is
+// still alive is looked at when the lane comes round again (raytrace_finish) — by then the answer is
+// there without waiting, and the few long paths' launches that follow run beside the other lanes' samples.
+constexpr uint32_t kSpeculativeLast = 7; // NOVA_HIP_SPECULATIVE_LAST, NOVA_HIP_POLL_STEP: A/B overrides
+constexpr uint32_t kPollStep = 2;        // iterations enqueued per look at the survivor count
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : dflt;
+}
+struct Pending {
+  bool active = false;
+  FrameArgs F;
+  const nova_bvh_node* bvh = nullptr;
+  const nova_triangle_data* triangles = nullptr;
+  uint32_t P = 0, next_it = 0, last_it = 0;
+  bool nee = false;
+};
+static Pending g_pending[kMaxLanes];
+
+static int raytrace_finish(Pending& pd) {
+  if (!pd.active) return 0;
+  pd.active = false;
+  if (pd.next_it > pd.last_it) return 0;
+  PackedScene* scene = nullptr;
+  int rc = get_scene(pd.bvh, pd.triangles, &scene);
+  if (rc) return rc;
+  while (pd.next_it <= pd.last_it) {
+    HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_queues + pd.next_it, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.chain_tail = nullptr;
+    if (*g.h_pinned == 0) break; // nobody left to take segment next_it
+    static const uint32_t step = std::max(1u, env_u32("NOVA_HIP_POLL_STEP", kPollStep));
+    for (uint32_t k = 0; k < step && pd.next_it <= pd.last_it; k++) {
+      rc = enqueue_iteration(*scene, pd.F, pd.P, pd.next_it++, pd.nee);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+// `sync` = false: everything is left enqueued on the library's stream (nova_hip_render_samples);
+// `pend` != NULL: see Pending.
 static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hip_image* temp_color1,
                          uint32_t width, uint32_t height, const nova_triangle_data* triangles,
                          const nova_triangle_meta* tri_meta, const nova_bvh_node* bvh,
                          const nova_area_light* lights, uint32_t num_lights,
                          const nova_hip_image* materials, const nova_hip_image* sky,
                          uint32_t denoise_available, nova_hip_image* albedo_feature1,
-                         nova_hip_image* normal_feature1, bool sync) {
+                         nova_hip_image* normal_feature1, bool sync, Pending* pend = nullptr) {
+  if (pend) pend->active = false;
   int rc = require_ctx();
   if (rc) return rc;
   if (!params || !triangles || !tri_meta || !bvh || width == 0 || height == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1104,7 +1172,6 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   // path counters and the queue heads of every iteration: one fill
   HIP_TRY(hipMemsetAsync(g.d_queues, 0, (kQueueWords + kHeadWords * (last_it + 1)) * sizeof(uint32_t), g.stream));
   const unsigned blocks = (P + 255) / 256;
-  const unsigned shade_blocks = (P + kShadeBlock - 1) / kShadeBlock;
   // primary rays = valid pixels of this rank's tiles
   for (uint32_t t = rank; t < n_tiles; t += ranks) {
     const uint32_t tx = t % tiles_x, ty = t / tiles_x;
@@ -1121,35 +1188,30 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   HIP_TRY(hipGetLastError());
 
 
-  for (uint32_t it = 0; it <= last_it; it++) {
-    const int in = it & 1, out = in ^ 1;
-    TraverseArgs T;
-    std::memset(&T, 0, sizeof(T));
-    T.ray_o = g.fb.ray_o[in];
-    T.ray_d = g.fb.ray_d[in];
-    T.hits = g.fb.hits;
-    T.n_items_ptr = g.d_queues + it;
-    T.kinds = (nee && it > 0) ? 3u : 1u;
-    T.stride = P;
-    T.queue_head = g.d_heads + kHeadWords * it;
-    rc = launch_traverse(*scene, T, it == 0);
+  const bool unbounded = F.max_depth == 0 && path_tracing;
+  uint32_t it = 0;
+  for (; it <= last_it; it++) {
+    static const uint32_t spec_last = env_u32("NOVA_HIP_SPECULATIVE_LAST", kSpeculativeLast);
+    if (pend && unbounded && it > spec_last) break; // the rest when the lane comes round again
+    rc = enqueue_iteration(*scene, F, P, it, nee);
     if (rc) return rc;
-    {
-      hipEvent_t e0 = nullptr;
-      span_begin(&e0);
-      hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(kShadeBlock), 0, g.stream, F, it, planes_of(in), planes_of(out),
-                         g.fb.ray_o[in], g.fb.ray_d[in], g.fb.hits, g.fb.ray_o[out], g.fb.ray_d[out]);
-      hipEvent_t e1 = span_end();
-      if (e0 && e1) g.ev_shade.push_back({ e0, e1 });
-    }
-    HIP_TRY(hipGetLastError());
     // unbounded mode: poll the survivor count now and then (paths die by miss / Russian roulette)
-    if (F.max_depth == 0 && path_tracing && it >= 3 && (it & 1u)) {
+    if (!pend && unbounded && it >= 3 && (it & 1u)) {
       HIP_TRY(hipMemcpyAsync(g.h_pinned, g.d_queues + it + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
       HIP_TRY(hipStreamSynchronize(g.stream));
       g.chain_tail = nullptr;
       if (*g.h_pinned == 0) break;
     }
+  }
+  if (pend) {
+    pend->active = true;
+    pend->F = F;
+    pend->bvh = bvh;
+    pend->triangles = triangles;
+    pend->P = P;
+    pend->next_it = it;
+    pend->last_it = last_it;
+    pend->nee = nee;
   }
   if (!sync) return 0;
   HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1360,32 +1422,51 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
       if (l != g.cur) (void) hipStreamSynchronize(g.lanes[l].stream);
   };
   int in = 0;
-  for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
-    const uint32_t r = (num_samples - 1 - k) % L; // the same for every sample of a lane
-    nova_hip_image* c1 = &one_color[r];
-    nova_hip_image* a1 = denoise_available ? &one_albedo[r] : nullptr;
-    nova_hip_image* n1 = denoise_available ? &one_normal[r] : nullptr;
-    rc = raytrace_impl(params, times[k], c1, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
-                       denoise_available, a1, n1, false);
-    if (rc) break;
+  const int lane0 = g.cur;
+  auto lane_of = [&](uint32_t k) { return static_cast<int>((static_cast<uint32_t>(lane0) + k) % L); };
+  // kernel_raytrace of sample k on the current lane; the planes are the same for every sample of a lane
+  auto start_sample = [&](uint32_t k) -> int {
+    const uint32_t r = (num_samples - 1 - k) % L;
+    return raytrace_impl(params, times[k], &one_color[r], width, height, triangles, tri_meta, bvh, lights, num_lights,
+                         materials, sky, denoise_available, denoise_available ? &one_albedo[r] : nullptr,
+                         denoise_available ? &one_normal[r] : nullptr, false, &g_pending[g.cur]);
+  };
+  // what is left of sample k (long paths of the unbounded mode), then its kernel_accumulate; called in
+  // the order of k, on sample k's lane
+  auto finish_sample = [&](uint32_t k) -> int {
+    const uint32_t r = (num_samples - 1 - k) % L;
+    int e = raytrace_finish(g_pending[g.cur]);
+    if (e) return e;
     if (L > 1 && k > 0) { // the running mean comes from the previous lane's kernel_accumulate
-      hipError_t e = hipStreamWaitEvent(g.stream, g.acc_done[(k - 1) & 1u], 0);
-      if (e != hipSuccess) { rc = static_cast<int>(e); break; }
+      hipError_t he = hipStreamWaitEvent(g.stream, g.acc_done[(k - 1) & 1u], 0);
+      if (he != hipSuccess) return static_cast<int>(he);
     }
-    rc = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, c1, a1, n1, &color[in],
-                         denoise_available ? &albedo[in] : nullptr, denoise_available ? &normal[in] : nullptr,
-                         &color[in ^ 1], denoise_available ? &albedo[in ^ 1] : nullptr,
-                         denoise_available ? &normal[in ^ 1] : nullptr, width, height, false);
-    if (rc) break;
+    e = accumulate_impl(first_sample_index + static_cast<int32_t>(k), denoise_available, &one_color[r],
+                        denoise_available ? &one_albedo[r] : nullptr, denoise_available ? &one_normal[r] : nullptr,
+                        &color[in], denoise_available ? &albedo[in] : nullptr, denoise_available ? &normal[in] : nullptr,
+                        &color[in ^ 1], denoise_available ? &albedo[in ^ 1] : nullptr,
+                        denoise_available ? &normal[in ^ 1] : nullptr, width, height, false);
+    if (e) return e;
     in ^= 1;
     if (L > 1 && k + 1 < num_samples) {
-      hipError_t e = hipEventRecord(g.acc_done[k & 1u], g.stream);
-      if (e != hipSuccess) { rc = static_cast<int>(e); break; }
-      switch_lane((g.cur + 1) % static_cast<int>(L));
+      hipError_t he = hipEventRecord(g.acc_done[k & 1u], g.stream);
+      if (he != hipSuccess) return static_cast<int>(he);
     }
+    return 0;
+  };
+  // lane by lane: finish the sample that was started there L samples ago, start the next one
+  for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
+    switch_lane(lane_of(k));
+    if (k >= L) rc = finish_sample(k - L);
+    if (rc == 0) rc = start_sample(k);
+  }
+  for (uint32_t k = num_samples > L ? num_samples - L : 0; k < num_samples && rc == 0; k++) {
+    switch_lane(lane_of(k));
+    rc = finish_sample(k);
   }
   if (rc) {
     wait_all();
+    for (auto& pd : g_pending) pd.active = false;
     collect_events();
     return rc;
   }

@@ -45,9 +45,10 @@ def make(sc, p, w, h, denoise):
 
 @pytest.mark.parametrize("fixture,cam,w,h,depth,denoise,fxaa,n", [
     ("cornell", S.CORNELL_CAMERA, 128, 128, 5, True, False, 5),   # odd count: final mean in temp2's plane
-    ("cornell", S.CORNELL_CAMERA, 96, 72, 0, False, True, 4),     # unbounded paths (host polls inside)
+    ("cornell", S.CORNELL_CAMERA, 96, 72, 0, False, True, 4),     # unbounded paths in a closed box (dozens of segments)
     ("knot_small", S.DRAGON_CAMERA, 320, 200, 5, True, True, 6),  # ragged tiles, even count
     ("soup50k", SOUP_CAMERA, 200, 130, 3, False, False, 1),       # a single sample
+    ("knot_small", S.DRAGON_CAMERA, 256, 160, 0, True, False, 7),  # unbounded: long paths finished when the lane comes round
 ])
 def test_fused_samples_leave_the_four_call_schedules_images(fixture, cam, w, h, depth, denoise, fxaa, n, request):
     sc = request.getfixturevalue(fixture)
