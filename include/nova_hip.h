@@ -270,7 +270,8 @@ typedef struct {
   uint64_t node_visits;       /* 64-byte node lines fetched (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t triangle_tests;    /* intersects_triangle evaluations (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t path_segments;     /* shaded hits */
-  double traverse_ms;         /* device time of traversal kernels since the last reset */
+  double traverse_ms;         /* device time of traversal kernels since the last reset (kernels of
+                                 nova_hip_render_samples overlap: there the sum exceeds wall time) */
   double shade_ms;            /* device time of generate/shade kernels since the last reset */
   uint64_t traverse_launches;
   double camera_traverse_ms;  /* the part of traverse_ms / traverse_launches spent on camera-ray */

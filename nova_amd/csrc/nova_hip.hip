@@ -191,6 +191,9 @@ void touch(const void* p) {
 hipEvent_t next_event() {
   static const bool off = std::getenv("NOVA_HIP_NO_EVENTS") != nullptr; // diagnostics: launches without timing events
   if (off) return nullptr;
+  // a call that enqueues thousands of kernels before it waits (nova_hip_render_samples with many
+  // samples) stops timing them rather than growing the pool without bound
+  if (g.ev_used >= 8192) return nullptr;
   if (g.ev_used == g.ev_pool.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
