@@ -102,7 +102,8 @@ enum {
   NOVA_HIP_E_UNKNOWN_BUFFER = -2,   /* device pointer not allocated by nova_hip_malloc */
   NOVA_HIP_E_BAD_SCENE = -3,        /* BVH does not parse (child index out of range, ...) */
   NOVA_HIP_E_NO_DEVICE = -4,        /* no HIP device / device ordinal out of range */
-  NOVA_HIP_E_TOO_LARGE = -5         /* request exceeds a documented maximum */
+  NOVA_HIP_E_TOO_LARGE = -5,        /* request exceeds a documented maximum */
+  NOVA_HIP_E_NOT_CACHED = -6        /* nova_hip_trace_rays_noalloc: no traversal layout cached for the buffers */
 };
 const char* nova_hip_error_string(int code);
 
@@ -243,6 +244,21 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
 int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
                         const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
                         nova_float4* hits, uint64_t num_rays);
+
+/* nova_hip_trace_rays for callers that cannot allocate.  No counterpart in the reference: it is for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments,
+ * same kernels and bit-identical hits, but the call makes no hipMalloc / hipFree / event or any other
+ * allocating call: the launch's queue heads and the traversal-stack entries beyond the LDS part live in
+ * a static device array of 32 MiB + 8 KiB that every GPU the library runs on holds until the process
+ * ends.  Conditions: nova_hip_init has run; the traversal layout of (bvh, triangles) is already cached,
+ * i.e. nova_hip_trace_rays, nova_hip_launch_raytrace or nova_hip_build_bvh_device has seen these buffers
+ * since they were last written (else NOVA_HIP_E_NOT_CACHED); num_rays < 2^31 and
+ * (stack depth the tree needs - 16) x (CUs x 5 x 256 threads) <= 8 Mi entries, i.e. depth <= 41 on the
+ * 256 CUs of an MI355X (else NOVA_HIP_E_TOO_LARGE).  All calls on one GPU share that array: calls that
+ * overlap on one GPU race.  Kernel times are not added to nova_hip_counters. */
+int nova_hip_trace_rays_noalloc(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
+                                const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
+                                nova_float4* hits, uint64_t num_rays);
 
 /* ---------------------------------------------------------------------------------------------
  * Backend options and counters (no counterpart in the reference, which has neither a bounce

@@ -27,12 +27,12 @@ EXPORTS = [
     "nova_hip_image_create", "nova_hip_image_destroy", "nova_hip_image_read",
     "nova_hip_image_write", "nova_hip_image_copy", "nova_hip_image_fill",
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
-    "nova_hip_render_samples", "nova_hip_trace_rays", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
+    "nova_hip_render_samples", "nova_hip_trace_rays", "nova_hip_trace_rays_noalloc", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
 ]
 # error codes (include/nova_hip.h)
-E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE = -1, -2, -3, -4, -5
+E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE, E_NOT_CACHED = -1, -2, -3, -4, -5, -6
 
 
 class NovaHipError(RuntimeError):
@@ -102,6 +102,7 @@ def load() -> ctypes.CDLL:
         "nova_hip_launch_post_process": [vp, vp, vp, u32, u32],
         "nova_hip_render_samples": [vp, vp, u32, i32, vp, u32, u32, vp, vp, vp, vp, u32, vp, vp, u32],
         "nova_hip_trace_rays": [vp, vp, vp, vp, vp, u64],
+        "nova_hip_trace_rays_noalloc": [vp, vp, vp, vp, vp, u64],
         "nova_hip_set_option": [ctypes.c_int, i64],
         "nova_hip_get_option": [ctypes.c_int, vp],
         "nova_hip_get_counters": [vp],
@@ -314,6 +315,13 @@ def trace_rays(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Bu
                num_rays: int):
     check(load().nova_hip_trace_rays(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
                                      hits.ptr, num_rays))
+
+
+def trace_rays_noalloc(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_flags: Buffer, hits: Buffer,
+                       num_rays: int):
+    """nova_hip_trace_rays_noalloc: the same, for callers that cannot allocate (include/nova_hip.h)."""
+    check(load().nova_hip_trace_rays_noalloc(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
+                                             hits.ptr, num_rays))
 
 
 class BuildStats(ctypes.Structure):

@@ -38,11 +38,20 @@ static_assert(offsetof(nova_scene_params, path_tracing) == 84, "SceneParams layo
 static_assert(sizeof(Node64) == 64, "Node64 layout");
 static_assert(sizeof(Node128) == 128, "Node128 layout");
 
+constexpr size_t kHeadWords = static_cast<size_t>(kSubQueues) * kSubQueueStride; // u32 words of one launch's queue heads
+
+// Scratch of nova_hip_trace_rays_noalloc, the one entry point that allocates nothing: the queue heads of
+// one traversal launch, then the traversal-stack entries beyond the LDS part ([entry][thread of the grid],
+// as HybridStack lays them out).  32 MiB + 8 KiB per GPU, held until the process ends.  On the host this
+// NAME is only a handle for hipGetSymbolAddress (nova_hip_init keeps the device address in
+// Ctx::scratch_ptr); host code never passes the name itself to a kernel or a copy.
+constexpr size_t kNoAllocSpillWords = static_cast<size_t>(8) << 20;
+static __device__ __align__(256) uint32_t scratch[kHeadWords + kNoAllocSpillWords];
+
 namespace {
 
 constexpr uint32_t kMaxIterations = 1024; // hard cap on path length in unbounded mode
 constexpr uint32_t kTileSize = 64;
-constexpr size_t kHeadWords = static_cast<size_t>(kSubQueues) * kSubQueueStride; // u32 words of one launch's queue heads
 constexpr size_t kQueueWords = 2048; // >= kMaxIterations + 2 path counters, a multiple of the head stride
 
 #define HIP_TRY(expr)                        \
@@ -120,6 +129,8 @@ struct Ctx {
   uint32_t* h_pinned = nullptr;          // readback word
   uint32_t* d_spill = nullptr;           // traversal stack entries beyond the LDS part
   size_t spill_words = 0;
+  uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
+  bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
   int64_t opt_max_depth = 0, opt_traversal = 0, opt_count_work = 0, opt_tile_rank = 0,
           opt_tile_ranks = 1, opt_kernel = 0, opt_tune = 0;
@@ -190,7 +201,7 @@ void touch(const void* p) {
 
 hipEvent_t next_event() {
   static const bool off = std::getenv("NOVA_HIP_NO_EVENTS") != nullptr; // diagnostics: launches without timing events
-  if (off) return nullptr;
+  if (off || g.no_alloc) return nullptr; // hipEventCreate allocates
   // a call that enqueues thousands of kernels before it waits (nova_hip_render_samples with many
   // samples) stops timing them rather than growing the pool without bound
   if (g.ev_used >= 8192) return nullptr;
@@ -553,6 +564,7 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   const size_t threads = static_cast<size_t>(blocks) * 256;
   const size_t words = need > static_cast<uint32_t>(kWideLdsStack) ? (need - kWideLdsStack) * threads : 0;
   if (words > g.spill_words) {
+    if (g.no_alloc) return NOVA_HIP_E_TOO_LARGE; // the static scratch array is what there is
     (void) hipStreamSynchronize(g.stream);
     (void) hipFree(g.d_spill);
     g.d_spill = nullptr;
@@ -736,6 +748,7 @@ const char* nova_hip_error_string(int code) {
     case NOVA_HIP_E_BAD_SCENE: return "nova_hip: malformed BVH";
     case NOVA_HIP_E_NO_DEVICE: return "nova_hip: no usable HIP device";
     case NOVA_HIP_E_TOO_LARGE: return "nova_hip: request exceeds a documented maximum";
+    case NOVA_HIP_E_NOT_CACHED: return "nova_hip: no traversal layout cached for these buffers (an allocating call must see them first)";
     default: break;
   }
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
@@ -758,6 +771,8 @@ int nova_hip_init(int device_ordinal) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NOVA_HIP_E_NO_DEVICE;
   if (device_ordinal < 0 || device_ordinal >= n) return NOVA_HIP_E_NO_DEVICE;
   HIP_TRY(hipSetDevice(device_ordinal));
+  // every GPU holds its own copy of `scratch` at its own address: resolved here, with the device current
+  HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&g.scratch_ptr), HIP_SYMBOL(scratch)));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
   g.num_cus = prop.multiProcessorCount;
@@ -1521,6 +1536,62 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
+  touch(hits);
+  return 0;
+}
+
+// nova_hip_trace_rays for callers that cannot allocate (HIP graph capture, serving loops): same kernels,
+// same arguments, but the queue heads and the stack-spill area live in the static `scratch` array, no
+// timing events are made and the traversal layout must already be cached.  Calls that overlap on one
+// GPU race on `scratch`.
+int nova_hip_trace_rays_noalloc(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
+                                const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
+                                nova_float4* hits, uint64_t num_rays) {
+  if (!g.ready || !g.scratch_ptr) return NOVA_HIP_E_NO_DEVICE; // nova_hip_init makes the context (it allocates)
+  if (!triangles || !bvh || !rays_point_tmax || !rays_dir_flags || !hits) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (num_rays == 0) return 0;
+  if (num_rays >= (1ull << 31)) return NOVA_HIP_E_TOO_LARGE;
+  const Alloc* a0 = find_alloc(rays_point_tmax);
+  const Alloc* a1 = find_alloc(rays_dir_flags);
+  const Alloc* a2 = find_alloc(hits);
+  const Alloc* ab = find_alloc(bvh);
+  const Alloc* at = find_alloc(triangles);
+  if (!a0 || !a1 || !a2 || !ab || !at) return NOVA_HIP_E_UNKNOWN_BUFFER;
+  if (a0->bytes < num_rays * 16 || a1->bytes < num_rays * 16 || a2->bytes < num_rays * 16)
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  const PackedScene* scene = nullptr;
+  for (const auto& s : g.scenes)
+    if (s.bvh_ptr == bvh && s.tri_ptr == triangles && s.bvh_version == ab->version && s.tri_version == at->version)
+      scene = &s;
+  if (!scene) return NOVA_HIP_E_NOT_CACHED;
+  uint32_t* const heads = g.scratch_ptr;
+  // the array keeps the last call's contents: the heads must start at zero (the spill area is written
+  // before it is read)
+  HIP_TRY(hipMemsetAsync(heads, 0, kHeadWords * sizeof(uint32_t), g.stream));
+  TraverseArgs T;
+  std::memset(&T, 0, sizeof(T));
+  T.ray_o = reinterpret_cast<const float4*>(rays_point_tmax);
+  T.ray_d = reinterpret_cast<const float4*>(rays_dir_flags);
+  T.hits = reinterpret_cast<float4*>(hits);
+  T.n_items_ptr = nullptr;
+  T.n_items_imm = static_cast<uint32_t>(num_rays);
+  T.kinds = 1;
+  T.stride = 0;
+  T.queue_head = heads;
+  uint32_t* const saved_spill = g.d_spill;
+  const size_t saved_words = g.spill_words;
+  g.d_spill = g.scratch_ptr + kHeadWords;
+  g.spill_words = kNoAllocSpillWords;
+  g.no_alloc = true;
+  g.chain_tail = nullptr;
+  int rc = launch_traverse(*scene, T, false);
+  g.no_alloc = false;
+  g.d_spill = saved_spill;
+  g.spill_words = saved_words;
+  const hipError_t e = hipStreamSynchronize(g.stream);
+  g.chain_tail = nullptr;
+  if (rc) return rc;
+  if (e != hipSuccess) return static_cast<int>(e);
   touch(hits);
   return 0;
 }
