@@ -10,9 +10,14 @@ Workload at N = 1 (BASELINE.json configs[1]): dragon scene — the real asset is
 reference tree, so its stand-in is used: a seeded 871,200-triangle displaced torus knot with the
 light, ground plane, camera and shading defaults of scene.toml's dragon section —
 1920x1080, path tracing, 4 bounces (max_depth 5), 1 spp per step.
-At N > 1 the frame grows with N (same view, N x the pixels: 4 GPUs = 3840x2160) and is cut into
-64x64 tiles dealt round-robin over ranks; no communication per sample; one RCCL all_gather of the
-finished uchar4 tiles inside the timed region ("scaling": "weak").
+At N > 1 the default is BASELINE.json configs[2] ("scaling": "strong"): the fireplace_room stand-in
+(closed room, ~142 k triangles, one ceiling light; the real asset is absent), a FIXED 3840x2160 frame
+cut into 64x64 tiles dealt round-robin over the N ranks, scene replicated, no communication per sample,
+and — inside the timed region — ONE RCCL all_gather of the finished tiles to rank 0 (uchar4 pixels; the
+float4 means + a whole-frame post-process on rank 0 with --anti-aliasing).  After the timed region rank 0
+renders the same K samples of the same frame alone and reports that as `same_workload_one_gpu`, the
+one-GPU point of this strong-scaling curve (the driver's own N = 1 run is configs[1], a different scene).
+--scaling weak keeps round 1's run: the dragon stand-in with a frame that grows with N.
 
 Prints ONE JSON line on rank 0.
 """
@@ -88,6 +93,11 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="skip the informational nova_hip_render_samples run after the timed region "
                          "(rocprofv3 --stats then averages the timed schedule's launches only)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1 only. strong (default): room stand-in, fixed 3840x2160 (BASELINE configs[2]); "
+                         "weak: dragon stand-in, frame grows with N")
+    ap.add_argument("--anti-aliasing", action="store_true",
+                    help="FXAA on: under tiles the float4 means are gathered and rank 0 post-processes the whole frame")
     ap.add_argument("--check-frame", action="store_true",
                     help="N > 1: rank 0 re-renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
@@ -121,14 +131,27 @@ def main():
     from nova_amd.raytracer import Raytracer
 
     capi.init(dev_index)  # fails loudly without the HIP library / a device
-    width, height = tiles.weak_scaling_dims(world)
+    strong = world > 1 and args.scaling == "strong"
+    width, height = (3840, 2160) if strong else tiles.weak_scaling_dims(world)
     if args.width and args.height:
         width, height = args.width, args.height
 
-    sc = S.dragon_standin(args.grid, args.grid)
-    cam = S.Camera(width=width, height=height, **S.DRAGON_CAMERA)
-    params = S.make_scene_params(cam, shading_diffuse=(1.0, 1.0, 1.0), shading_metallic=0.4,
-                                 shading_roughness=0.1, path_tracing=True, num_samples=args.steps)
+    if strong:
+        sc = S.room_standin()
+        cam = S.Camera(width=width, height=height, **S.ROOM_CAMERA)
+        params = S.make_scene_params(cam, path_tracing=True, num_samples=args.steps,
+                                     anti_aliasing=args.anti_aliasing, **S.ROOM_SHADING)
+        scene_name = "fireplace_room stand-in (closed room with seeded clutter, one ceiling light"
+    else:
+        sc = S.dragon_standin(args.grid, args.grid)
+        cam = S.Camera(width=width, height=height, **S.DRAGON_CAMERA)
+        params = S.make_scene_params(cam, shading_diffuse=(1.0, 1.0, 1.0), shading_metallic=0.4,
+                                     shading_roughness=0.1, path_tracing=True, num_samples=args.steps,
+                                     anti_aliasing=args.anti_aliasing)
+        scene_name = "dragon stand-in (displaced torus knot incl. ground+light"
+    # under a tile partition FXAA needs the whole frame: the ranks skip kernel_post_process per sample and
+    # rank 0 runs it once on the gathered means (tiles.finish_frame)
+    per_sample_post = not (world > 1 and args.anti_aliasing)
     rt = Raytracer(dev_index)
     rt.set_scene(sc, params, width, height)
     capi.set_option(capi.OPT_MAX_DEPTH, MAX_DEPTH)
@@ -143,24 +166,22 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        rt.raytrace(rt.step_time(SEED), read_back=False)
-    def local_frame():
-        t = tiles.image_as_tensor(rt.color_img, torch.device("cuda", dev_index))
-        return t if coll_device == "cuda" else t.cpu()
-
+        rt.raytrace(rt.step_time(SEED), read_back=False, post_process=per_sample_post)
     if dist is not None:  # warm the collective too
-        tiles.gather_frame(local_frame(), width, height, rank, world)
+        tiles.finish_frame(rt, rank, world, coll_device)
     rt.start()
     capi.reset_counters()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rt.raytrace(rt.step_time(SEED), read_back=False)
+        rt.raytrace(rt.step_time(SEED), read_back=False, post_process=per_sample_post)
     frame = None
     if dist is not None:
-        frame = tiles.gather_frame(local_frame(), width, height, rank, world)
+        tiles.finish_frame(rt, rank, world, coll_device)  # rank 0's color_img = the whole frame
     barrier()
     dt = time.perf_counter() - t0
+    if dist is not None and rank == 0:
+        frame = rt.color_img.read()
 
     k = capi.counters()
     local = np.array([k["rays_primary"], k["rays_bounce"], k["rays_shadow"], k["traverse_launches"]], np.float64)
@@ -205,17 +226,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"dragon stand-in (displaced torus knot, {sc.triangles.shape[0]} triangles incl. "
-                            f"ground+light, BVH {sc.bvh.shape[0]} nodes), {width}x{height}, path tracing, "
-                            f"max_depth {MAX_DEPTH} (4 bounces), 1 spp per step, fixed seed {SEED}+sample",
+                "workload": f"{scene_name}; {sc.triangles.shape[0]} triangles, BVH {sc.bvh.shape[0]} nodes), "
+                            f"{width}x{height}, path tracing, max_depth {MAX_DEPTH} (4 bounces), 1 spp per step, "
+                            f"fixed seed {SEED}+sample",
                 "frame": [width, height],
                 "tiles": "64x64 round-robin over ranks" if world > 1 else "single GPU",
-                "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step",
+                "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step"
+                            + ("" if world == 1 else "; one all_gather of the finished tiles per run"
+                               + (" (float4 means, FXAA + tone-map of the whole frame on rank 0)" if args.anti_aliasing
+                                  else " (uchar4 pixels)")),
             },
             "rays_per_step": rays // args.steps,
             "mrays_per_s_primary": round(rays_primary / dt / 1e6, 2),
@@ -266,18 +290,33 @@ def main():
         out["roofline"] = roof
         if fused is not None:
             out["fused_samples"] = fused
-        if args.check_frame and frame is not None:
-            # the gathered frame against this rank rendering every tile itself, same seeds
+        if world > 1:
+            # the one-GPU point of the same workload (and, with --check-frame, the frame itself): rank 0
+            # renders every tile alone, same seeds, while the other ranks wait at the final barrier
             capi.set_option(capi.OPT_TILE_RANK, 0)
             capi.set_option(capi.OPT_TILE_RANKS, 1)
             rt.start()
+            rt.raytrace(rt.step_time(SEED), read_back=False)  # frame buffers grow to the whole frame here
+            rt.start()
+            capi.reset_counters()
+            capi.synchronize()
+            a0 = time.perf_counter()
             for _ in range(args.steps):
                 rt.raytrace(rt.step_time(SEED), read_back=False)
             capi.synchronize()
-            alone = tiles.image_as_tensor(rt.color_img, torch.device("cuda", dev_index)).cpu()
-            out["frame_check"] = bool((alone == frame.cpu()).all())
+            adt = time.perf_counter() - a0
+            ka = capi.counters()
+            arays = ka["rays_primary"] + ka["rays_bounce"] + ka["rays_shadow"]
+            out["same_workload_one_gpu"] = {"ms_per_step": round(adt / args.steps * 1e3, 4),
+                                            "value": round(arays / adt / 1e6, 2), "unit": "Mrays/s",
+                                            "rays_per_step": int(arays // args.steps)}
+            if args.check_frame and frame is not None:
+                alone = rt.color_img.read()
+                out["frame_check"] = bool((alone == frame).all())
+                out["frame_bytes_differing"] = int((alone != frame).sum())
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()  # rank 0's one-GPU run of the same workload ends here
         dist.destroy_process_group()
 
 

@@ -117,7 +117,10 @@ int nova_hip_init(int device_ordinal);
 int nova_hip_device_count(int* count);
 int nova_hip_device_name(char* out, size_t out_bytes);
 int nova_hip_synchronize(void);
-int nova_hip_shutdown(void); /* frees every cached scene and work buffer of the current device */
+/* Frees everything the library owns on the device (cached scenes, work buffers, streams, events) and
+ * forgets the device: a later nova_hip_init may pick another one.  Buffers and images the caller made
+ * stay valid until the caller frees them. */
+int nova_hip_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Buffers.  Replace nova::Buffer<T> (src/backend/cuda/types/buffer.hpp:11-86): constructor
@@ -154,7 +157,7 @@ typedef struct nova_hip_image {
   uint32_t normalized_coords;
 } nova_hip_image;
 
-/* `host_data` may be NULL (uninitialised image). */
+/* `host_data` may be NULL: the image then starts as zeros. */
 int nova_hip_image_create(nova_hip_image** image, uint32_t texel_bytes, uint32_t width,
                           uint32_t height, uint32_t layers, uint32_t address_mode,
                           uint32_t filter_mode, uint32_t normalized_coords,
@@ -233,6 +236,23 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
                             uint32_t denoise_available);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tile stacks for the multi-GPU gather.  No counterpart in the reference (one device,
+ * src/backend/opencl/accelerator/accelerator.cpp:11-25); SURVEY.md §8e.  A frame is cut into 64x64 tiles,
+ * tile t belongs to rank t % ranks.  nova_hip_tiles_pack writes rank's tiles of a float4 or uchar4 image
+ * into one contiguous stack [k][64][64] (tile id = rank + k * ranks; zeros beyond the image border and the
+ * last tile) of nova_hip_tiles_stack_bytes bytes — the send buffer of ONE collective per final frame
+ * (ncclAllGather / ncclSend-Recv to the root).  nova_hip_tiles_unpack scatters the `ranks` stacks, laid
+ * out one after the other as an all-gather leaves them, into the whole image.  stack_dev / stacks_dev are
+ * any device pointers of sufficient size (the collective's buffers need not come from nova_hip_malloc).
+ * With anti_aliasing: gather the float4 running means (temp_color2), unpack on the root, set
+ * NOVA_HIP_OPT_TILE_RANKS = 1 there and run nova_hip_launch_post_process on the whole frame.  Without:
+ * post-process per rank and gather the uchar4 pixels (a quarter of the bytes).
+ * ------------------------------------------------------------------------------------------- */
+uint64_t nova_hip_tiles_stack_bytes(uint32_t width, uint32_t height, uint32_t ranks, uint32_t texel_bytes);
+int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev);
+int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev);
+
+/* ---------------------------------------------------------------------------------------------
  * Ray batches.  find_intersection (kernels/raytrace.hpp:38-102) over an array of rays, for
  * callers that generate their own rays (BASELINE config 4: 16 M incoherent rays per batch).
  * Each ray is built as the reference builds it at every call site (raytrace.hpp:132,216,239):
@@ -270,8 +290,11 @@ enum {
                                    1 = reference walk: fixed order, no culling (validation) */
   NOVA_HIP_OPT_COUNT_WORK = 3,  /* 1 = also count node visits / triangle tests (slower) */
   NOVA_HIP_OPT_TILE_RANK = 4,   /* image-tile partition for multi-GPU: this process renders the */
-  NOVA_HIP_OPT_TILE_RANKS = 5,  /* tiles with (tile_id % ranks) == rank; tiles are 64x64 pixels; */
-                                /* pixels of other tiles are left untouched by kernel_raytrace */
+  NOVA_HIP_OPT_TILE_RANKS = 5,  /* tiles with (tile_id % ranks) == rank; tiles are 64x64 pixels.  All three kernels
+                                   then touch this rank's pixels only (its tiles, plus the few pixels of neighbouring
+                                   tiles that its own pixels' bilinear reads weight with more than 0) and leave the
+                                   rest of every image as it is; kernel_post_process and nova_hip_render_samples
+                                   refuse anti_aliasing (FXAA reads across tiles): see nova_hip_tiles_pack */
   NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* internal A/B switch between traversal kernel variants */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */

@@ -31,11 +31,18 @@ public:
   //   NOVA_HIP_DEVICE      device ordinal (default 0)
   //   NOVA_HIP_MAX_DEPTH   max path segments per sample, 0 = unbounded like the reference
   //   NOVA_HIP_FIXED_SEED  replaces the wall-clock `time` argument by seed + launch counter
+  //   NOVA_HIP_TILE_RANK / NOVA_HIP_TILE_RANKS   multi-GPU: this process (one per GPU) renders the 64x64
+  //                        tiles t with t % RANKS == RANK (nova_hip.h: NOVA_HIP_OPT_TILE_RANK/RANKS)
   Accelerator() {
     const char* dev = std::getenv("NOVA_HIP_DEVICE");
     HIP_CHECK_AND_THROW(nova_hip_init(dev ? std::atoi(dev) : 0));
     if (const char* d = std::getenv("NOVA_HIP_MAX_DEPTH")) {
       HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_MAX_DEPTH, std::atoll(d)));
+    }
+    if (const char* n = std::getenv("NOVA_HIP_TILE_RANKS")) {
+      const char* r = std::getenv("NOVA_HIP_TILE_RANK");
+      HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_TILE_RANKS, std::atoll(n)));
+      HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_TILE_RANK, r ? std::atoll(r) : 0));
     }
     if (const char* s = std::getenv("NOVA_HIP_FIXED_SEED")) {
       fixed_seed = true;

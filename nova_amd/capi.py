@@ -30,6 +30,7 @@ EXPORTS = [
     "nova_hip_render_samples", "nova_hip_trace_rays", "nova_hip_trace_rays_noalloc", "nova_hip_set_option", "nova_hip_get_option", "nova_hip_get_counters",
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
+    "nova_hip_tiles_stack_bytes", "nova_hip_tiles_pack", "nova_hip_tiles_unpack",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE, E_NOT_CACHED = -1, -2, -3, -4, -5, -6
@@ -110,7 +111,11 @@ def load() -> ctypes.CDLL:
         "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_build_bvh_device": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_validate_scene_pack": [vp, vp, vp],
+        "nova_hip_tiles_pack": [vp, u32, u32, vp],
+        "nova_hip_tiles_unpack": [vp, u32, vp],
     }
+    lib.nova_hip_tiles_stack_bytes.restype = u64
+    lib.nova_hip_tiles_stack_bytes.argtypes = [u32, u32, u32, u32]
     lib.nova_hip_bvh_max_nodes.restype = u64
     lib.nova_hip_bvh_max_nodes.argtypes = [u64]
     for name, args in sig.items():
@@ -322,6 +327,20 @@ def trace_rays_noalloc(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_f
     """nova_hip_trace_rays_noalloc: the same, for callers that cannot allocate (include/nova_hip.h)."""
     check(load().nova_hip_trace_rays_noalloc(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
                                              hits.ptr, num_rays))
+
+
+def tiles_stack_bytes(width: int, height: int, ranks: int, texel_bytes: int) -> int:
+    return int(load().nova_hip_tiles_stack_bytes(width, height, ranks, texel_bytes))
+
+
+def tiles_pack(image: Image, rank: int, ranks: int, stack_ptr: int):
+    """nova_hip_tiles_pack: `rank`'s 64x64 tiles of `image` into the contiguous stack at device pointer stack_ptr."""
+    check(load().nova_hip_tiles_pack(image.handle, rank, ranks, stack_ptr))
+
+
+def tiles_unpack(image: Image, ranks: int, stacks_ptr: int):
+    """nova_hip_tiles_unpack: the all-gathered stacks at device pointer stacks_ptr into the whole image."""
+    check(load().nova_hip_tiles_unpack(image.handle, ranks, stacks_ptr))
 
 
 class BuildStats(ctypes.Structure):

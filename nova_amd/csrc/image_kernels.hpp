@@ -19,17 +19,43 @@ struct AccumulateArgs {
   const float4 *color1, *albedo1, *normal1, *prev_color, *prev_albedo, *prev_normal;
   float4 *color2, *albedo2, *normal2;
   uint32_t width, height;
+  const uint8_t* mask; // tile partition: per pixel, bit 0 = own tile, bit 1 = halo pixel kept as well; null = every pixel
 };
+
+// sample_linear<false> at a pixel centre under a tile partition: texels this rank does not keep (mask 0) read
+// as 0 without being loaded.  Every tap with a non-zero weight is kept by construction (TilePlan), so for
+// finite images this is sample_linear<false> bit for bit — and whatever another rank's pixels hold in this
+// rank's memory (never written here; possibly NaN) cannot reach its own pixels through a zero weight.
+NV_DEV V3 sample_kept(const float4* p, const uint8_t* mask, int w, int h, float s, float t) {
+  const float u = s * static_cast<float>(w), v = t * static_cast<float>(h);
+  const int i0 = static_cast<int>(__builtin_floorf(u - 0.5f)), j0 = static_cast<int>(__builtin_floorf(v - 0.5f));
+  const int i1 = i0 + 1, j1 = j0 + 1;
+  const float a = (u - 0.5f) - __builtin_floorf(u - 0.5f);
+  const float b = (v - 0.5f) - __builtin_floorf(v - 0.5f);
+  auto tx = [&](int i, int j) {
+    if (i < 0 || j < 0 || i >= w || j >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t k = static_cast<size_t>(j) * w + i;
+    return mask[k] ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  const float4 t00 = tx(i0, j0), t10 = tx(i1, j0), t01 = tx(i0, j1), t11 = tx(i1, j1);
+  const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  return { fma_(t11.x, w11, fma_(t01.x, w01, fma_(t00.x, w00, t10.x * w10))),
+           fma_(t11.y, w11, fma_(t01.y, w01, fma_(t00.y, w00, t10.y * w10))),
+           fma_(t11.z, w11, fma_(t01.z, w01, fma_(t00.z, w00, t10.z * w10))) };
+}
 
 __global__ __launch_bounds__(256) void k_accumulate(AccumulateArgs A) {
   const float si = static_cast<float>(A.sample_index), si1 = static_cast<float>(A.sample_index + 1);
   const uint32_t n_pixels = A.width * A.height;
   const int w = static_cast<int>(A.width), h = static_cast<int>(A.height);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
+    if (A.mask && A.mask[i] == 0) continue; // another rank's pixel
     const uint32_t y = i / A.width, x = i - y * A.width;
     const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
     const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
-    auto ld = [&](const float4* p) { return sample_linear<false>(ImageView { p, w, h, 1 }, u, v, 0); };
+    auto ld = [&](const float4* p) {
+      return A.mask ? sample_kept(p, A.mask, w, h, u, v) : sample_linear<false>(ImageView { p, w, h, 1 }, u, v, 0);
+    };
     V3 c = ld(A.color1);
     V3 a { 0.f, 0.f, 0.f }, n { 0.f, 0.f, 0.f };
     if (A.denoise) {
@@ -135,18 +161,22 @@ struct PostArgs {
   uint32_t width, height;
   float exposure;
   uint32_t anti_aliasing;
+  const uint8_t* mask; // as in AccumulateArgs; only own pixels (bit 0) are written
 };
 
 __global__ __launch_bounds__(256) void k_post_process(PostArgs A) {
   const uint32_t n = A.width * A.height;
   const float inv_w = 1.0f / static_cast<float>(A.width), inv_h = 1.0f / static_cast<float>(A.height);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (A.mask && (A.mask[i] & 1u) == 0) continue;
     V3 c;
     const uint32_t y = i / A.width, x = i - y * A.width;
     const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
     const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
     if (A.anti_aliasing) {
       c = fxaa(A.color2, inv_w, inv_h, u, v);
+    } else if (A.mask) {
+      c = sample_kept(A.color2.texels, A.mask, A.color2.w, A.color2.h, u, v);
     } else {
       c = sample_linear<false>(A.color2, u, v, 0);
     }
@@ -160,6 +190,40 @@ __global__ __launch_bounds__(256) void k_post_process(PostArgs A) {
     px.z = static_cast<unsigned char>(static_cast<int>(o.z));
     px.w = 255;
     A.pixels[i] = px;
+  }
+}
+
+// Tile stacks for the multi-GPU gather: rank r's tiles (tile id = r + k * ranks, 64x64 texels each, zero
+// beyond the image border and beyond the last tile) as one contiguous [k][64][64] array, and back.
+template <typename T>
+__global__ __launch_bounds__(256) void k_tiles_pack(const T* image, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                    uint32_t n_tiles, uint32_t rank, uint32_t ranks, uint32_t per_rank, T* stack) {
+  const size_t total = static_cast<size_t>(per_rank) * 4096u;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const uint32_t k = static_cast<uint32_t>(i >> 12), q = static_cast<uint32_t>(i & 4095u);
+    const uint32_t tile = rank + k * ranks;
+    T v = {};
+    if (tile < n_tiles) {
+      const uint32_t x = (tile % tiles_x) * 64u + (q & 63u), y = (tile / tiles_x) * 64u + (q >> 6);
+      if (x < width && y < height) v = image[static_cast<size_t>(y) * width + x];
+    }
+    stack[i] = v;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_tiles_unpack(T* image, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                      uint32_t n_tiles, uint32_t ranks, uint32_t per_rank, const T* stacks) {
+  const size_t total = static_cast<size_t>(ranks) * per_rank * 4096u;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const uint32_t q = static_cast<uint32_t>(i & 4095u);
+    const size_t rk = i >> 12;
+    const uint32_t r = static_cast<uint32_t>(rk / per_rank), k = static_cast<uint32_t>(rk - static_cast<size_t>(r) * per_rank);
+    const uint32_t tile = r + k * ranks;
+    if (tile >= n_tiles) continue;
+    const uint32_t x = (tile % tiles_x) * 64u + (q & 63u), y = (tile / tiles_x) * 64u + (q >> 6);
+    if (x < width && y < height) image[static_cast<size_t>(y) * width + x] = stacks[i];
   }
 }
 

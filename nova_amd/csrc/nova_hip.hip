@@ -114,6 +114,21 @@ struct Lane {
   hipEvent_t chain_tail = nullptr;
 };
 
+// What a rank of a tile partition keeps besides its own tiles.  kernel_accumulate and kernel_post_process read
+// every pixel through a LINEAR sampler at the pixel centre (kernels/kernels.cu:59-64, :103-110); in float the
+// centre (x + 0.5) / W * W is not always x + 0.5, so at a few columns and rows a neighbouring texel gets a
+// weight of ~1e-6 instead of 0.  Where such a neighbour lies in another rank's tile this rank renders and
+// accumulates it as well ("extra" pixels: the closure of its own pixels under "is read with a non-zero
+// weight"), so that its own pixels hold exactly the single-GPU frame's values.  Zero-weight taps are not
+// followed (0 * finite = 0): what a NaN texel of another rank's tile would do to its neighbour through them
+// (the reference's behaviour for, e.g., the normal feature of sky pixels) is not reproduced across tiles.
+struct TilePlan {
+  uint32_t w = 0, h = 0, rank = 0, ranks = 1;
+  uint8_t* d_mask = nullptr;   // [h][w]: bit 0 = own tile, bit 1 = extra pixel
+  uint32_t* d_extra = nullptr; // pixel ids (y * w + x) of the extra pixels, row-major order
+  uint32_t n_extra = 0;
+};
+
 struct Ctx {
   bool ready = false;
   int device = -1;
@@ -129,6 +144,7 @@ struct Ctx {
   uint32_t* h_pinned = nullptr;          // readback word
   uint32_t* d_spill = nullptr;           // traversal stack entries beyond the LDS part
   size_t spill_words = 0;
+  TilePlan plan;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -155,6 +171,17 @@ struct Ctx {
 
 Ctx g;
 std::mutex g_mutex;
+
+// a sample of nova_hip_render_samples whose first iterations are enqueued on its lane (see raytrace_impl)
+struct Pending {
+  bool active = false;
+  FrameArgs F;
+  const nova_bvh_node* bvh = nullptr;
+  const nova_triangle_data* triangles = nullptr;
+  uint32_t P = 0, next_it = 0, last_it = 0;
+  bool nee = false;
+};
+Pending g_pending[kMaxLanes];
 
 int require_ctx() {
   if (!g.ready) {
@@ -194,8 +221,17 @@ void drop_scenes_using(const void* p) {
   }
 }
 
+// new contents at p: the allocation that CONTAINS p gets a new version (a write into the middle of a
+// registered BVH or triangle buffer must invalidate the cached traversal layout too)
 void touch(const void* p) {
   auto it = g.allocs.find(p);
+  if (it == g.allocs.end()) {
+    const char* c = static_cast<const char*>(p);
+    for (it = g.allocs.begin(); it != g.allocs.end(); ++it) {
+      const char* base = static_cast<const char*>(it->first);
+      if (c >= base && c < base + it->second.bytes) break;
+    }
+  }
   if (it != g.allocs.end()) it->second.version = g.next_version++;
 }
 
@@ -732,6 +768,82 @@ PathPlanes planes_of(int side) {
            fb.planes[side][3], fb.planes[side][4], fb.planes[side][5] };
 }
 
+// texels (other than x itself) that the pixel-centre sample of pixel x reads with a non-zero weight along one
+// axis of n texels: the arithmetic of k_accumulate / sample_linear<false>, operation for operation
+void axis_deps(uint32_t n, std::vector<std::vector<uint32_t>>& deps) {
+  deps.assign(n, {});
+  for (uint32_t x = 0; x < n; x++) {
+    const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(n);
+    const float uw = u * static_cast<float>(n);
+    const float fl = std::floor(uw - 0.5f);
+    const float a = (uw - 0.5f) - fl;
+    const int i0 = static_cast<int>(fl);
+    const int cand[2] = { i0, i0 + 1 };
+    const float wt[2] = { 1.0f - a, a };
+    for (int k = 0; k < 2; k++)
+      if (wt[k] != 0.0f && cand[k] >= 0 && cand[k] < static_cast<int>(n) && cand[k] != static_cast<int>(x))
+        deps[x].push_back(static_cast<uint32_t>(cand[k]));
+  }
+}
+
+std::vector<uint32_t> axis_closure(uint32_t lo, uint32_t hi, const std::vector<std::vector<uint32_t>>& deps) {
+  std::vector<uint32_t> set;
+  std::vector<uint8_t> in(deps.size(), 0);
+  for (uint32_t x = lo; x <= hi; x++) { set.push_back(x); in[x] = 1; }
+  for (size_t k = 0; k < set.size(); k++)
+    for (uint32_t t : deps[set[k]])
+      if (!in[t]) { in[t] = 1; set.push_back(t); }
+  return set;
+}
+
+void free_tile_plan() {
+  (void) hipFree(g.plan.d_mask);
+  (void) hipFree(g.plan.d_extra);
+  g.plan = TilePlan {};
+}
+
+// the plan of the current partition options for a width x height frame (made on the host, cached)
+int ensure_tile_plan(uint32_t width, uint32_t height) {
+  const uint32_t rank = static_cast<uint32_t>(g.opt_tile_rank), ranks = static_cast<uint32_t>(g.opt_tile_ranks);
+  TilePlan& P = g.plan;
+  if (P.d_mask && P.w == width && P.h == height && P.rank == rank && P.ranks == ranks) return 0;
+  HIP_TRY(hipDeviceSynchronize()); // kernels of any lane may still read the old one
+  free_tile_plan();
+  std::vector<std::vector<uint32_t>> dx, dy;
+  axis_deps(width, dx);
+  axis_deps(height, dy);
+  const uint32_t tiles_x = (width + kTileSize - 1) / kTileSize, tiles_y = (height + kTileSize - 1) / kTileSize;
+  std::vector<uint8_t> mask(static_cast<size_t>(width) * height, 0);
+  for (uint32_t t = rank; t < tiles_x * tiles_y; t += ranks) {
+    const uint32_t x0 = (t % tiles_x) * kTileSize, y0 = (t / tiles_x) * kTileSize;
+    for (uint32_t y = y0; y < std::min(y0 + kTileSize, height); y++)
+      std::memset(&mask[static_cast<size_t>(y) * width + x0], 1, std::min(kTileSize, width - x0));
+  }
+  std::vector<uint32_t> extra;
+  for (uint32_t t = rank; t < tiles_x * tiles_y; t += ranks) {
+    const uint32_t x0 = (t % tiles_x) * kTileSize, y0 = (t / tiles_x) * kTileSize;
+    const uint32_t x1 = std::min(x0 + kTileSize, width) - 1, y1 = std::min(y0 + kTileSize, height) - 1;
+    const std::vector<uint32_t> cols = axis_closure(x0, x1, dx), rows = axis_closure(y0, y1, dy);
+    if (cols.size() == x1 - x0 + 1 && rows.size() == y1 - y0 + 1) continue;
+    for (uint32_t y : rows)
+      for (uint32_t x : cols) {
+        uint8_t& m = mask[static_cast<size_t>(y) * width + x];
+        if (m == 0) m = 2;
+      }
+  }
+  for (size_t i = 0; i < mask.size(); i++)
+    if (mask[i] == 2) extra.push_back(static_cast<uint32_t>(i));
+  HIP_TRY(hipMalloc(&P.d_mask, mask.size()));
+  hipError_t e = hipMemcpy(P.d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&P.d_extra, std::max<size_t>(extra.size(), 1) * sizeof(uint32_t));
+  if (e == hipSuccess && !extra.empty())
+    e = hipMemcpy(P.d_extra, extra.data(), extra.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { free_tile_plan(); return static_cast<int>(e); }
+  P.w = width; P.h = height; P.rank = rank; P.ranks = ranks;
+  P.n_extra = static_cast<uint32_t>(extra.size());
+  return 0;
+}
+
 bool float_image_ok(const nova_hip_image* im, uint32_t w, uint32_t h) {
   return im && im->data && im->texel_bytes == 16 && im->width == w && im->height == h && im->layers >= 1;
 }
@@ -809,36 +921,38 @@ int nova_hip_synchronize(void) {
 int nova_hip_shutdown(void) {
   std::lock_guard<std::mutex> lock(g_mutex);
   if (!g.ready) return 0;
-  (void) hipStreamSynchronize(g.stream);
+  (void) hipDeviceSynchronize();
   collect_events();
+  switch_lane(0); // the context's own fields are lane 0 again; lanes[1..] hold the others
   for (auto& s : g.scenes) free_scene(s);
-  (void) hipFree(g.d_spill);
-  g.d_spill = nullptr;
-  g.spill_words = 0;
   g.scenes.clear();
-  for (int s = 0; s < 2; s++) {
-    for (int k = 0; k < 6; k++) { (void) hipFree(g.fb.planes[s][k]); g.fb.planes[s][k] = nullptr; }
-    (void) hipFree(g.fb.ray_o[s]); g.fb.ray_o[s] = nullptr;
-    (void) hipFree(g.fb.ray_d[s]); g.fb.ray_d[s] = nullptr;
-  }
-  (void) hipFree(g.fb.hits);
-  g.fb.hits = nullptr;
-  g.fb.capacity = 0;
-  for (int l = 0; l < g.lanes_ready; l++) {
-    if (l == g.cur) continue;
+  free_tile_plan();
+  free_frame_buffers(g.fb);
+  (void) hipFree(g.d_spill);
+  (void) hipFree(g.d_queues);
+  (void) hipFree(g.d_counters);
+  (void) hipHostFree(g.h_pinned);
+  (void) hipStreamDestroy(g.stream);
+  for (int l = 1; l < g.lanes_ready; l++) {
     Lane& o = g.lanes[l];
-    (void) hipStreamSynchronize(o.stream);
-    uint64_t bc[4] = { 0, 0, 0, 0 }; // its ray counts stay in the totals
-    if (add_block_counters(o.fb, bc) == 0)
-      for (int q = 0; q < 4; q++) g.folded[q] += bc[q];
     free_frame_buffers(o.fb);
     (void) hipFree(o.d_spill);
-    o.d_spill = nullptr;
-    o.spill_words = 0;
+    (void) hipFree(o.d_queues);
+    (void) hipHostFree(o.h_pinned);
+    if (o.stream) (void) hipStreamDestroy(o.stream);
   }
   for (auto& lane : g.stage)
-    for (auto& p : lane) { (void) hipFree(p); p = nullptr; }
-  g.stage_bytes = 0;
+    for (auto& p : lane) (void) hipFree(p);
+  for (auto& e : g.acc_done)
+    if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : g.ev_pool) (void) hipEventDestroy(e);
+  for (auto& pd : g_pending) pd = Pending {};
+  // buffers from nova_hip_malloc belong to the caller and stay valid; the registry goes with them
+  std::unordered_map<const void*, Alloc> allocs = std::move(g.allocs);
+  const uint64_t next_version = g.next_version;
+  g = Ctx {};
+  g.allocs = std::move(allocs);
+  g.next_version = next_version;
   return 0;
 }
 
@@ -923,10 +1037,10 @@ int nova_hip_image_create(nova_hip_image** image, uint32_t texel_bytes, uint32_t
   const size_t bytes = static_cast<size_t>(width) * height * layers * texel_bytes;
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, bytes));
-  if (host_data) {
-    hipError_t e = hipMemcpy(p, host_data, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void) hipFree(p); return static_cast<int>(e); }
-  }
+  // an image without initial data starts as zeros: under a tile partition kernel_raytrace never writes
+  // other ranks' pixels, and stale NaN/Inf words there must not reach this rank's readers
+  hipError_t e = host_data ? hipMemcpy(p, host_data, bytes, hipMemcpyHostToDevice) : hipMemset(p, 0, bytes);
+  if (e != hipSuccess) { (void) hipFree(p); return static_cast<int>(e); }
   nova_hip_image* im = new nova_hip_image { p, width, height, layers, texel_bytes, address_mode, filter_mode, normalized_coords };
   *image = im;
   return 0;
@@ -1084,15 +1198,6 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* e = std::getenv(name);
   return e && *e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : dflt;
 }
-struct Pending {
-  bool active = false;
-  FrameArgs F;
-  const nova_bvh_node* bvh = nullptr;
-  const nova_triangle_data* triangles = nullptr;
-  uint32_t P = 0, next_it = 0, last_it = 0;
-  bool nee = false;
-};
-static Pending g_pending[kMaxLanes];
 
 static int raytrace_finish(Pending& pd) {
   if (!pd.active) return 0;
@@ -1152,8 +1257,14 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   const uint32_t rank = static_cast<uint32_t>(g.opt_tile_rank), ranks = static_cast<uint32_t>(g.opt_tile_ranks);
   const uint32_t n_my_tiles = n_tiles > rank ? (n_tiles - rank + ranks - 1) / ranks : 0;
   if (n_my_tiles == 0) return 0;
-  if (static_cast<uint64_t>(n_my_tiles) * 4096ull * 3ull >= (1ull << 31)) return NOVA_HIP_E_TOO_LARGE;
-  const uint32_t P = n_my_tiles * 4096u;
+  uint32_t n_extra = 0;
+  if (ranks > 1) {
+    rc = ensure_tile_plan(width, height);
+    if (rc) return rc;
+    n_extra = g.plan.n_extra;
+  }
+  if ((static_cast<uint64_t>(n_my_tiles) * 4096ull + n_extra) * 3ull >= (1ull << 31)) return NOVA_HIP_E_TOO_LARGE;
+  const uint32_t P = n_my_tiles * 4096u + n_extra;
   rc = ensure_frame_buffers(P);
   if (rc) return rc;
 
@@ -1167,6 +1278,8 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   F.tile_ranks = ranks;
   F.tiles_x = tiles_x;
   F.n_my_tiles = n_my_tiles;
+  F.extra_pixels = ranks > 1 ? g.plan.d_extra : nullptr;
+  F.n_extra = n_extra;
   F.meta = tri_meta;
   F.lights = lights;
   F.num_lights = num_lights;
@@ -1196,6 +1309,7 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
     const uint32_t w = std::min(kTileSize, width - tx * kTileSize), hgt = std::min(kTileSize, height - ty * kTileSize);
     g.host_primary += static_cast<uint64_t>(w) * hgt;
   }
+  g.host_primary += n_extra;
   {
     hipEvent_t e0 = nullptr;
     span_begin(&e0);
@@ -1290,6 +1404,13 @@ static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
   A.normal2 = ptr(normal_feature2);
   A.width = width;
   A.height = height;
+  A.mask = nullptr;
+  if (g.opt_tile_ranks > 1) { // this rank's pixels only (its tiles + their halo)
+    if (g.opt_tile_rank >= g.opt_tile_ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
+    rc = ensure_tile_plan(width, height);
+    if (rc) return rc;
+    A.mask = g.plan.d_mask;
+  }
   const unsigned blocks = std::min<unsigned>((width * height + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
   g.chain_tail = nullptr; // a later timing span must not start before this kernel
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, g.stream, A);
@@ -1325,6 +1446,17 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
   A.height = height;
   A.exposure = params->exposure;
   A.anti_aliasing = params->anti_aliasing ? 1u : 0u;
+  A.mask = nullptr;
+  if (g.opt_tile_ranks > 1) {
+    // FXAA reads up to ~26 pixels along an edge (kernels/anti_aliasing.hpp:99-116), i.e. other ranks'
+    // pixels: gather the float means (nova_hip_tiles_pack / _unpack) and post-process the whole frame
+    // on one rank with NOVA_HIP_OPT_TILE_RANKS = 1 instead
+    if (A.anti_aliasing) return NOVA_HIP_E_INVALID_ARGUMENT;
+    if (g.opt_tile_rank >= g.opt_tile_ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
+    rc = ensure_tile_plan(width, height);
+    if (rc) return rc;
+    A.mask = g.plan.d_mask;
+  }
   const unsigned n = width * height;
   const unsigned blocks = std::min<unsigned>((n + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
   hipLaunchKernelGGL(k_post_process, dim3(blocks), dim3(256), 0, g.stream, A);
@@ -1340,10 +1472,16 @@ static int ensure_lanes(int lanes, size_t plane_bytes, bool features) {
   while (g.lanes_ready < lanes) { // lane numbers are handed out in order; the current one may be any of them
     Lane& o = g.lanes[g.lanes_ready];
     o = Lane {};
-    HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&o.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t)));
+    hipError_t e = hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&o.d_queues, (kQueueWords + kHeadWords * (kMaxIterations + 2)) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&o.h_pinned, 64, hipHostMallocDefault);
+    if (e != hipSuccess) { // nothing of a half-made lane is kept: a retry starts from Lane {}
+      if (o.stream) (void) hipStreamDestroy(o.stream);
+      (void) hipFree(o.d_queues);
+      o = Lane {};
+      return static_cast<int>(e);
+    }
     o.d_heads = o.d_queues + kQueueWords;
-    HIP_TRY(hipHostMalloc(&o.h_pinned, 64, hipHostMallocDefault));
     g.lanes_ready++;
   }
   if (plane_bytes > g.stage_bytes) {
@@ -1391,6 +1529,7 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
     for (const nova_hip_image* im : need)
       if (!float_image_ok(im, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
   }
+  if (g.opt_tile_ranks > 1 && params->anti_aliasing) return NOVA_HIP_E_INVALID_ARGUMENT; // see nova_hip_launch_post_process
   const size_t plane = static_cast<size_t>(width) * height * 16;
   // lanes: NOVA_HIP_LANES=1..4 (A/B); default below
   static const int env_lanes = [] {
@@ -1500,6 +1639,53 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
   wait_all(); // the other lanes are done already: their last kernels were waited for by this one's
   collect_events();
   return rc;
+}
+
+// ---- tile stacks for the multi-GPU gather ------------------------------------------------------
+uint64_t nova_hip_tiles_stack_bytes(uint32_t width, uint32_t height, uint32_t ranks, uint32_t texel_bytes) {
+  if (width == 0 || height == 0 || ranks == 0) return 0;
+  const uint64_t n_tiles = static_cast<uint64_t>((width + kTileSize - 1) / kTileSize) * ((height + kTileSize - 1) / kTileSize);
+  return (n_tiles + ranks - 1) / ranks * (kTileSize * kTileSize) * texel_bytes;
+}
+
+int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!image || !image->data || !stack_dev || ranks == 0 || rank >= ranks || image->layers != 1 ||
+      (image->texel_bytes != 16 && image->texel_bytes != 4))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  const uint32_t tiles_x = (image->width + kTileSize - 1) / kTileSize, tiles_y = (image->height + kTileSize - 1) / kTileSize;
+  const uint32_t n_tiles = tiles_x * tiles_y, per_rank = (n_tiles + ranks - 1) / ranks;
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>(static_cast<size_t>(per_rank) * 16, static_cast<size_t>(g.num_cus) * 16));
+  if (image->texel_bytes == 16)
+    hipLaunchKernelGGL(k_tiles_pack<uint4>, dim3(blocks), dim3(256), 0, g.stream, static_cast<const uint4*>(image->data),
+                       image->width, image->height, tiles_x, n_tiles, rank, ranks, per_rank, static_cast<uint4*>(stack_dev));
+  else
+    hipLaunchKernelGGL(k_tiles_pack<uint32_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<const uint32_t*>(image->data),
+                       image->width, image->height, tiles_x, n_tiles, rank, ranks, per_rank, static_cast<uint32_t*>(stack_dev));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!image || !image->data || !stacks_dev || ranks == 0 || image->layers != 1 ||
+      (image->texel_bytes != 16 && image->texel_bytes != 4))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  const uint32_t tiles_x = (image->width + kTileSize - 1) / kTileSize, tiles_y = (image->height + kTileSize - 1) / kTileSize;
+  const uint32_t n_tiles = tiles_x * tiles_y, per_rank = (n_tiles + ranks - 1) / ranks;
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>(static_cast<size_t>(per_rank) * ranks * 16, static_cast<size_t>(g.num_cus) * 16));
+  if (image->texel_bytes == 16)
+    hipLaunchKernelGGL(k_tiles_unpack<uint4>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint4*>(image->data),
+                       image->width, image->height, tiles_x, n_tiles, ranks, per_rank, static_cast<const uint4*>(stacks_dev));
+  else
+    hipLaunchKernelGGL(k_tiles_unpack<uint32_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint32_t*>(image->data),
+                       image->width, image->height, tiles_x, n_tiles, ranks, per_rank, static_cast<const uint32_t*>(stacks_dev));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
 }
 
 // ---- ray batches -------------------------------------------------------------------------------

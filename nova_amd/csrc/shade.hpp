@@ -43,6 +43,11 @@ struct FrameArgs {
   uint32_t time;
   uint32_t width, height;
   uint32_t tile_rank, tile_ranks, tiles_x, n_my_tiles;
+  // under a tile partition: pixels of other ranks' tiles that this rank renders as well, because the
+  // pixel-centre bilinear reads of kernel_accumulate / kernel_post_process give them a non-zero weight
+  // for one of its own pixels (TilePlan in nova_hip.hip); paths n_my_tiles * 4096 .. + n_extra - 1
+  const uint32_t* extra_pixels;
+  uint32_t n_extra;
   const nova_triangle_meta* meta;
   const nova_area_light* lights;
   uint32_t num_lights;
@@ -253,6 +258,12 @@ NV_DEV V3 power_heuristic(V3 p, V3 s) {
 // path index -> pixel: 64x64 image tiles dealt round-robin over ranks; inside a tile 8x8 blocks,
 // so that the 64 lanes of a wave start as one coherent 8x8 pixel block.
 NV_DEV bool path_pixel(const FrameArgs& F, uint32_t p, uint32_t& x, uint32_t& y) {
+  if (p >= F.n_my_tiles * 4096u) {
+    const uint32_t pixel = F.extra_pixels[p - F.n_my_tiles * 4096u];
+    y = pixel / F.width;
+    x = pixel - y * F.width;
+    return true;
+  }
   const uint32_t t = p >> 12, q = p & 4095u;
   const uint32_t tile = F.tile_rank + t * F.tile_ranks;
   const uint32_t tx = tile % F.tiles_x, ty = tile / F.tiles_x;
@@ -265,7 +276,7 @@ NV_DEV bool path_pixel(const FrameArgs& F, uint32_t p, uint32_t& x, uint32_t& y)
 // Stage 1: camera rays.  kernels/kernels.cu:23-27 (seed) and kernels/raytrace.hpp:117-127.
 __global__ __launch_bounds__(256) void k_generate(FrameArgs F, PathPlanes S, float4* ray_o, float4* ray_d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t total = F.n_my_tiles * 4096u;
+  const uint32_t total = F.n_my_tiles * 4096u + F.n_extra;
   if (p == 0) F.n_active[0] = total;
   if (p >= total) return;
   uint32_t x, y;

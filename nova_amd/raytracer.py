@@ -87,14 +87,17 @@ class Raytracer:
                                  self.height)
 
     # raytracer.cpp:169-262 (without the OIDN hand-off, whose library is absent)
-    def raytrace(self, time: int, read_back: bool = True):
+    def raytrace(self, time: int, read_back: bool = True, post_process: bool = True):
+        """post_process=False: a rank of a tile partition with FXAA on leaves kernel_post_process to
+        tiles.finish_frame (it must see the whole frame)."""
         self.kernel_raytrace(time)
         self.kernel_accumulate()
         self.prev_color_img.copy_from(self.temp_color_img2)
         if self.denoise_available:
             self.prev_albedo_img.copy_from(self.albedo_img2)
             self.prev_normal_img.copy_from(self.normal_img2)
-        self.kernel_post_process()
+        if post_process:
+            self.kernel_post_process()
         self.sample_index += 1
         return self.color_img.read() if read_back else None
 

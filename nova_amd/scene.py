@@ -529,6 +529,17 @@ def dragon_standin(nu=660, nv=660) -> Scene:
     return build_scene(verts, rect_lights=light, ground=ground, sky=analytic_sky())
 
 
+ROOM_CAMERA = dict(position=[0.85, 0.05, 0.9], target=[-0.3, -0.25, -0.4], up=[0.0, 1.0, 0.0], fovy=55.0)
+ROOM_SHADING = dict(shading_metallic=0.1, shading_roughness=0.6)
+
+
+def room_standin(n_objects=140, res=23, seed=3) -> Scene:
+    """BASELINE config 3 stand-in (assets/fireplace_room/fireplace_room.glb is absent): a closed room
+    with seeded clutter (~142 k triangles) lit by one emissive ceiling quad; see room_scene."""
+    verts, meta, em = room_scene(n_objects, res, seed)
+    return build_scene(verts, meta=meta, emissive=em)
+
+
 # ------------------------------------------------------------------------------------------------
 # The reference's hex dump format for FlatBVHNode / Triangle (src/bvh/bvh.cpp:251-281,
 # src/intersectables/triangle.cpp:27-55): the float bit patterns as hex words separated by blanks.

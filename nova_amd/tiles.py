@@ -9,7 +9,13 @@ tiles are gathered to rank 0 with one collective (RCCL all_gather over equal-siz
 every peer has its own xGMI link to the root, so this is one hop).
 
 One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU
-tests).  Results are bit-identical to a single-GPU render of the same frame.
+tests).  The production path is ``finish_frame``: the C ABI packs a rank's tiles into one contiguous
+stack (``nova_hip_tiles_pack``), ONE all_gather moves the stacks, rank 0 scatters them into the whole
+image (``nova_hip_tiles_unpack``).  With FXAA the float4 running means are gathered and rank 0
+post-processes the whole frame (FXAA reads up to ~26 px across tile borders, reference
+``kernels/anti_aliasing.hpp:99-116``); without it every rank post-processes its own pixels and the
+uchar4 pixels are gathered (a quarter of the bytes).  ``pack_tiles``/``unpack_tiles`` are the same
+layout in torch, used by the CPU (gloo) tests.
 """
 from __future__ import annotations
 
@@ -81,6 +87,51 @@ def gather_frame(local_frame, width: int, height: int, rank: int, ranks: int, gr
     if rank != 0:
         return None
     return unpack_tiles(gathered.view((ranks,) + tuple(mine.shape)), width, height, ranks)
+
+
+def gather_image(image, rank: int, ranks: int, coll_device: str = "cuda", group=None):
+    """All ranks: ``image`` (capi.Image, float4 or uchar4) holds valid pixels in this rank's tiles.
+    After the call rank 0's image holds every rank's tiles.  One collective."""
+    import torch
+    import torch.distributed as dist
+
+    from . import capi
+
+    nbytes = capi.tiles_stack_bytes(image.width, image.height, ranks, image.texel_bytes)
+    mine = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    capi.tiles_pack(image, rank, ranks, mine.data_ptr())  # returns after the device has finished
+    if ranks == 1:
+        capi.tiles_unpack(image, 1, mine.data_ptr())
+        return
+    send = mine if coll_device == "cuda" else mine.cpu()
+    gathered = torch.empty(ranks * nbytes, dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(gathered, send, group=group)  # rank r's stack lands at [r*n, (r+1)*n)
+    if rank != 0:
+        return
+    if coll_device != "cuda":
+        gathered = gathered.cuda()
+    torch.cuda.synchronize()  # the collective runs on torch's stream, the unpack on the library's
+    capi.tiles_unpack(image, ranks, gathered.data_ptr())
+
+
+def finish_frame(rt, rank: int, ranks: int, coll_device: str = "cuda", group=None) -> bool:
+    """The final frame of a tile-partitioned render: afterwards rank 0's ``rt.color_img`` holds the whole
+    post-processed frame (returns True there).  ``rt`` is a nova_amd.raytracer.Raytracer whose running
+    mean (``temp_color_img2``) is up to date on this rank's tiles."""
+    from . import capi
+
+    if bool(rt.params["anti_aliasing"]):
+        gather_image(rt.temp_color_img2, rank, ranks, coll_device, group)
+        if rank == 0:
+            capi.set_option(capi.OPT_TILE_RANKS, 1)  # the image is whole now
+            try:
+                rt.kernel_post_process()
+            finally:
+                capi.set_option(capi.OPT_TILE_RANKS, ranks)
+    else:
+        rt.kernel_post_process()
+        gather_image(rt.color_img, rank, ranks, coll_device, group)
+    return rank == 0
 
 
 class DeviceArray:

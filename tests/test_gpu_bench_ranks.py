@@ -15,21 +15,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_gpu_gather_the_same_frame():
+def run_bench(ranks, extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, NOVA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "96", "--width", "448", "--height", "256",
-           "--check-frame"]
+           "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--width", "448", "--height", "256",
+           "--check-frame"] + extra
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads(line)
+
+
+def test_two_ranks_on_one_gpu_gather_the_same_frame():
+    out = run_bench(2, ["--scaling", "weak", "--grid", "96"])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["frame_check"] is True
     assert out["value"] > 0 and out["rays_per_step"] >= 448 * 256
     assert out["config"]["tiles"].startswith("64x64")
+
+
+def test_three_ranks_strong_scaling_with_fxaa_gather_the_same_frame():
+    """The default N > 1 run (BASELINE configs[2]: room stand-in, fixed frame, "strong") with FXAA on: the
+    float4 means are gathered and rank 0 post-processes the whole frame — bytes equal to one GPU's."""
+    out = run_bench(3, ["--anti-aliasing"])
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong"
+    assert out["frame_check"] is True, out.get("frame_bytes_differing")
+    assert "fireplace_room stand-in" in out["config"]["workload"]
+    one = out["same_workload_one_gpu"]
+    assert one["ms_per_step"] > 0 and abs(one["rays_per_step"] - out["rays_per_step"]) < 0.02 * out["rays_per_step"]
