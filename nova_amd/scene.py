@@ -294,14 +294,13 @@ def _parse_mtl(path: str) -> dict:
     return mats
 
 
-def load_obj(path: str):
-    """Returns (verts[n,9], meta[n], emissive[n,3]); geometry normalised to [-1,1] like assimp's
-    AI_CONFIG_PP_PTV_NORMALIZE; quads/polygons fan-triangulated; missing normals = face normals;
-    degenerate triangles dropped (src/model/model.cpp:128-134)."""
+def read_obj_indexed(path: str):
+    """The data of an OBJ file as arrays: positions, normals, texture coordinates, per-corner indices of the
+    fan-triangulated faces (-1 = absent), material number per triangle, material names, MTL dictionary."""
     pos, nrm, tex = [], [], []
-    faces = []  # (material, [(vi, ti, ni), ...])
-    mats = {}
-    cur = None
+    tri_v, tri_t, tri_n, tri_m = [], [], [], []
+    names, mats = [], {}
+    cur = -1
     with open(path, "r", errors="replace") as f:
         for line in f:
             t = line.split("#")[0].split()
@@ -316,7 +315,10 @@ def load_obj(path: str):
             elif t[0] == "mtllib":
                 mats.update(_parse_mtl(os.path.join(os.path.dirname(path), " ".join(t[1:]))))
             elif t[0] == "usemtl":
-                cur = " ".join(t[1:])
+                name = " ".join(t[1:])
+                if name not in names:
+                    names.append(name)
+                cur = names.index(name)
             elif t[0] == "f":
                 idx = []
                 for w in t[1:]:
@@ -327,44 +329,98 @@ def load_obj(path: str):
                     idx.append((vi + len(pos) if vi < 0 else vi - 1,
                                 (ti + len(tex) if ti < 0 else ti - 1) if ti else -1,
                                 (ni + len(nrm) if ni < 0 else ni - 1) if ni else -1))
-                faces.append((cur, idx))
-    P = np.asarray(pos, np.float32)
+                for k in range(1, len(idx) - 1):
+                    tri = (idx[0], idx[k], idx[k + 1])
+                    tri_v.append([c[0] for c in tri])
+                    tri_t.append([c[1] for c in tri])
+                    tri_n.append([c[2] for c in tri])
+                    tri_m.append(cur)
+    return dict(pos=np.asarray(pos, np.float32).reshape(-1, 3), nrm=np.asarray(nrm, np.float32).reshape(-1, 3),
+                tex=np.asarray(tex, np.float32).reshape(-1, 2), tri_v=np.asarray(tri_v, np.int32).reshape(-1, 3),
+                tri_t=np.asarray(tri_t, np.int32).reshape(-1, 3), tri_n=np.asarray(tri_n, np.int32).reshape(-1, 3),
+                tri_m=np.asarray(tri_m, np.int32)), names, mats
+
+
+def assemble_mesh(d, tangents=False):
+    """Indexed OBJ data -> (verts[n,9], meta[n], kept): geometry normalised to [-1,1] like assimp's
+    AI_CONFIG_PP_PTV_NORMALIZE (src/model/model.cpp:22-28); missing normals = face normals; degenerate
+    triangles dropped (model.cpp:128-134).  tangents=True adds a per-face tangent frame from the texture
+    coordinates, the bitangent fixed as model.cpp:151-163 does (cross(n, t), sign of the computed one);
+    assimp's CalcTangentSpace smooths per vertex instead, so this is same-shaped input, not assimp's output.
+    `kept` = indices into the input triangles."""
+    P = d["pos"]
     lo, hi = P.min(0), P.max(0)
-    d = hi - lo
-    div = np.float32(max(d) * 0.5)
-    P = ((P - (lo + d * np.float32(0.5))) / div).astype(np.float32)
-    N = np.asarray(nrm, np.float32).reshape(-1, 3)
-    T = np.asarray(tex, np.float32).reshape(-1, 2)
-    tv, tn, tt, tm = [], [], [], []
-    for mat, idx in faces:
-        for k in range(1, len(idx) - 1):
-            tri = (idx[0], idx[k], idx[k + 1])
-            v = np.stack([P[i[0]] for i in tri])
-            L = sorted([np.linalg.norm(v[0] - v[1]), np.linalg.norm(v[1] - v[2]),
-                        np.linalg.norm(v[0] - v[2])])
-            if L[0] + L[1] <= L[2]:
-                continue
-            tv.append(v.reshape(9))
-            if all(i[2] >= 0 for i in tri):
-                tn.append(np.stack([N[i[2]] for i in tri]))
-            else:
-                tn.append(None)
-            tt.append(np.stack([T[i[1]] if i[1] >= 0 else np.zeros(2, np.float32) for i in tri]))
-            tm.append(mat)
-    verts = np.asarray(tv, np.float32)
+    ext = hi - lo
+    P = ((P - (lo + ext * np.float32(0.5))) / np.float32(max(ext) * 0.5)).astype(np.float32)
+    v = P[d["tri_v"]]  # [n, 3, 3]
+    e01 = np.linalg.norm(v[:, 0] - v[:, 1], axis=1)
+    e12 = np.linalg.norm(v[:, 1] - v[:, 2], axis=1)
+    e02 = np.linalg.norm(v[:, 0] - v[:, 2], axis=1)
+    L = np.sort(np.stack([e01, e12, e02], 1), axis=1)
+    kept = np.flatnonzero(~(L[:, 0] + L[:, 1] <= L[:, 2]))
+    v = v[kept]
+    verts = np.ascontiguousarray(v.reshape(-1, 9), np.float32)
     n = verts.shape[0]
     meta = default_meta(n)
     fn = face_normals(verts)
+    tn = d["tri_n"][kept]
+    N = d["nrm"] if d["nrm"].shape[0] else np.zeros((1, 3), np.float32)
+    ns = np.where((tn >= 0).all(1)[:, None, None], N[np.maximum(tn, 0)], fn[:, None, :]).astype(np.float32)
+    ns = (ns / np.maximum(np.linalg.norm(ns, axis=2, keepdims=True), 1e-30)).astype(np.float32)
+    meta["normal1"], meta["normal2"], meta["normal3"] = ns[:, 0], ns[:, 1], ns[:, 2]
+    tt = d["tri_t"][kept]
+    T = d["tex"] if d["tex"].shape[0] else np.zeros((1, 2), np.float32)
+    uv = np.where((tt >= 0)[:, :, None], T[np.maximum(tt, 0)], 0).astype(np.float32)
+    meta["texture_coord1"], meta["texture_coord2"], meta["texture_coord3"] = uv[:, 0], uv[:, 1], uv[:, 2]
+    if tangents:
+        e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+        d1, d2 = uv[:, 1] - uv[:, 0], uv[:, 2] - uv[:, 0]
+        det = (d1[:, 0] * d2[:, 1] - d2[:, 0] * d1[:, 1]).astype(np.float32)
+        det = np.where(det == 0, np.float32(1.0), det)
+        tan = ((e1 * d2[:, 1:2] - e2 * d1[:, 1:2]) / det[:, None]).astype(np.float32)
+        bit = ((e2 * d1[:, 0:1] - e1 * d2[:, 0:1]) / det[:, None]).astype(np.float32)
+        tan = (tan / np.maximum(np.linalg.norm(tan, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        for k, nk in enumerate(("1", "2", "3")):
+            fb = np.cross(ns[:, k], tan).astype(np.float32)
+            fb = np.where(((fb * bit).sum(1) < 0)[:, None], -fb, fb).astype(np.float32)
+            meta["tangent" + nk], meta["bitangent" + nk] = tan, fb
+    return verts, meta, kept
+
+
+def load_obj(path: str):
+    """Returns (verts[n,9], meta[n], emissive[n,3], [material name per triangle, MTL dict]); see
+    read_obj_indexed / assemble_mesh."""
+    d, names, mats = read_obj_indexed(path)
+    verts, meta, kept = assemble_mesh(d)
+    n = verts.shape[0]
     em = np.zeros((n, 3), np.float32)
+    tm = [names[m] if m >= 0 else None for m in d["tri_m"][kept]]
     for i in range(n):
-        ns = tn[i] if tn[i] is not None else np.stack([fn[i]] * 3)
-        ns = ns / np.maximum(np.linalg.norm(ns, axis=1, keepdims=True), 1e-30)
-        meta["normal1"][i], meta["normal2"][i], meta["normal3"][i] = ns
-        meta["texture_coord1"][i], meta["texture_coord2"][i], meta["texture_coord3"][i] = tt[i]
         m = mats.get(tm[i], {"Kd": (0.6, 0.6, 0.6), "Ke": (0, 0, 0)})
         meta["kD"][i] = m["Kd"]
         em[i] = m["Ke"]
     return verts, meta, em, [tm, mats]
+
+
+def aircraft_scene(sky_size=(1024, 512)) -> Scene:
+    """BASELINE config 5 on its own asset, from the committed data fixture tests/golden/aircraft.npz
+    (tests/golden/make_aircraft_fixture.py: assets/aircraft/aircraft.obj + the two JPEGs its MTL uses that
+    are in the reference tree; the third, `E-45 _col.jpg`, is absent — .MISSING_LARGE_BLOBS — and replaced
+    by a seeded procedural albedo).  Layers as Model::process_mesh loads them (src/model/model.cpp:76-89):
+    per material its diffuse map (sRGB -> linear on uint8, material_loader.cpp:24-33) and its normal map;
+    uint8 -> float4 / 255 (material_loader.cpp:69-76).  Sky: the analytic stand-in (lakeside_4k.hdr absent)."""
+    z = np.load(os.path.join(_HERE, "..", "tests", "golden", "aircraft.npz"))
+    d = {k: z[k] for k in ("pos", "nrm", "tex", "tri_v", "tri_t", "tri_n", "tri_m")}
+    verts, meta, kept = assemble_mesh(d, tangents=True)
+    mat = d["tri_m"][kept]
+    meta["kD"] = (1.0, 1.0, 1.0)  # both materials: Kd 1 1 1
+    meta["diffuse_index"] = z["diffuse_layer"][mat]
+    meta["normal_index"] = z["normal_layer"][mat]
+    layers = (z["layers"].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    return build_scene(verts, meta=meta, materials=layers, sky=analytic_sky(*sky_size))
+
+
+AIRCRAFT_CAMERA = dict(position=[-1.6, 0.9, 1.9], target=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -443,6 +499,19 @@ def room_scene(n_objects=140, res=23, seed=3):
              c * (S * T)[..., None] + d * ((1 - S) * T)[..., None])
         return grid_to_triangles(P, wrap_u=False, wrap_v=False)
 
+    def facing(tris, toward=None, away_from=None):
+        """Winding such that the face normal points toward a point (room surfaces: the room's centre;
+        the reference shades with the stored normals as they are, kernels/material.hpp:37-41, so a wall
+        wound outwards would never receive light) or away from one (objects: their centre)."""
+        v = tris.reshape(-1, 3, 3)
+        nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+        cen = v.mean(1)
+        ref = (np.asarray(toward, np.float32) - cen) if toward is not None else (cen - np.asarray(away_from, np.float32))
+        flip = (nrm * ref).sum(1) < 0
+        v = v.copy()
+        v[flip] = v[flip][:, [0, 2, 1]]
+        return np.ascontiguousarray(v.reshape(-1, 9), np.float32)
+
     X, Y, Z = 1.0, 0.6, 1.0
     walls = [
         ([-X, -Y, -Z], [X, -Y, -Z], [X, -Y, Z], [-X, -Y, Z], (0.55, 0.5, 0.45)),   # floor
@@ -453,17 +522,17 @@ def room_scene(n_objects=140, res=23, seed=3):
         ([X, -Y, -Z], [X, Y, -Z], [X, Y, Z], [X, -Y, Z], (0.2, 0.45, 0.2)),       # right
     ]
     for a, b, c, d, kd in walls:
-        q = quad(a, b, c, d)
+        q = facing(quad(a, b, c, d), toward=[0.0, 0.0, 0.0])
         parts.append(q)
         kds.append(np.tile(np.asarray(kd, np.float32), (q.shape[0], 1)))
     for _ in range(n_objects):
         r = rng.uniform(0.03, 0.12)
         cpos = [rng.uniform(-X + r, X - r), rng.uniform(-Y + r, 0.1), rng.uniform(-Z + r, Z - r)]
-        m = bumpy_sphere(cpos, r, res, res, rng)
+        m = facing(bumpy_sphere(cpos, r, res, res, rng), away_from=cpos)
         parts.append(m)
         kds.append(np.tile(rng.uniform(0.2, 0.9, 3).astype(np.float32), (m.shape[0], 1)))
-    light = quad([-0.3, Y - 1e-3, -0.3], [0.3, Y - 1e-3, -0.3], [0.3, Y - 1e-3, 0.3],
-                 [-0.3, Y - 1e-3, 0.3], n=1)
+    light = facing(quad([-0.3, Y - 1e-3, -0.3], [0.3, Y - 1e-3, -0.3], [0.3, Y - 1e-3, 0.3],
+                        [-0.3, Y - 1e-3, 0.3], n=1), toward=[0.0, 0.0, 0.0])
     parts.append(light)
     kds.append(np.tile(np.float32([0.78, 0.78, 0.78]), (light.shape[0], 1)))
     verts = np.concatenate(parts)

@@ -72,11 +72,9 @@ if "c1" in which:  # Cornell box 512^2, 1 spp, primary + shadow (path tracing wi
     frames(rt, 20, 1, "C1 cornell 512^2, 1 segment")
 
 if "c3" in which:  # fireplace_room stand-in, 3840x2160
-    verts, meta, em = S.room_scene()
-    sc = S.build_scene(verts, meta=meta, emissive=em)
+    sc = S.room_standin()
     w, h = 3840, 2160
-    cam = dict(position=[0.85, 0.05, 0.9], target=[-0.3, -0.25, -0.4], up=[0, 1, 0], fovy=55.0)
-    p = S.make_scene_params(S.Camera(width=w, height=h, **cam), shading_metallic=0.1, shading_roughness=0.6)
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.ROOM_CAMERA), **S.ROOM_SHADING)
     rt = Raytracer(0)
     rt.set_scene(sc, p, w, h)
     print("C3 room stand-in: %d triangles, %d lights" % (sc.triangles.shape[0], sc.num_lights))

@@ -242,7 +242,7 @@ def test_random_scenes_short_soak():
     assert "0 different" in res.stdout.splitlines()[-1]
 
 
-@pytest.mark.parametrize("name", ["cornell", "soup2k", "knot96", "room_with_light_and_ground"])
+@pytest.mark.parametrize("name", ["cornell", "soup2k", "knot96", "knot40_with_light_and_ground", "room20"])
 def test_callers_flat_tree_is_packed_on_the_device_like_the_host_packer(name, monkeypatch):
     """A FlatBVHNode[] uploaded by the caller (Nova's own host-built tree): the first launch validates it
     and makes the traversal layout on the device; the host packer must give the same words."""
@@ -253,6 +253,8 @@ def test_callers_flat_tree_is_packed_on_the_device_like_the_host_packer(name, mo
         sc = S.build_scene(S.soup(2000, seed=2, edge=0.1))
     elif name == "knot96":
         sc = S.dragon_standin(96, 96)
+    elif name == "room20":
+        sc = S.room_standin(n_objects=20, res=9)  # closed room, emissive ceiling quad (TRI lights)
     else:
         sc = S.dragon_standin(40, 40)
     bvh, tris = capi.Buffer(sc.bvh), capi.Buffer(sc.triangles)
