@@ -287,3 +287,16 @@ def test_malformed_flat_trees_still_get_the_host_packers_verdict():
     # not check that: the device front end declines it and the host packer walks it as before
     b = sc.bvh.copy(); b["bottom_num_right"][0, 3] += 1.0
     capi.trace_rays(tris, capi.Buffer(b), ro, rd, hits, 64)
+
+
+def test_device_built_triangle_data_equals_the_reference_glm_vectors():
+    """tests/golden/ref_pins.npz holds the Woop matrices the REFERENCE's own glm calls give (oracle/_ref, built from
+    the reference's files; tests/golden/make_ref_pins.py): k_emit_triangles must reproduce them bit for bit."""
+    from tests.helpers import golden
+    g = golden("ref_pins.npz")
+    _, tris, order, _ = capi.build_bvh(g["verts"])
+    ref = g["woop"][order]
+    got = np.ascontiguousarray(tris, np.float32).reshape(-1, 12)
+    fin = np.isfinite(ref).all(1)
+    assert fin.mean() > 0.95
+    assert (got[fin].view(np.uint32) == ref[fin].view(np.uint32)).all()
