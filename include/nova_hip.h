@@ -236,6 +236,28 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
                             uint32_t denoise_available);
 
 /* ---------------------------------------------------------------------------------------------
+ * Denoise hand-off, the device half.  Replaces, in Raytracer::raytrace
+ * (src/core/raytracer.cpp:211-242), read_image2D x3 + flatten<float4, float, 3> x3 (:216-221) by
+ * nova_hip_denoise_read, and pack<float4, float, 3> + write_image2D (:240-241) by nova_hip_denoise_write
+ * (templates: src/vector/vector_utils.hpp:8-51).  The float4 -> 3-float conversion runs on the device, the
+ * three planes cross PCIe as ONE copy of 36 bytes per pixel (the reference moves 48 and then walks them on
+ * the host) into pinned host memory the library owns; the denoiser (OIDN: setImage takes plain pointers,
+ * :224-227) reads `color`, `albedo`, `normal` there and writes `output`, which nova_hip_denoise_write sends
+ * back and expands into `color`'s float4 texels with w = 0, as pack's value-initialised vector leaves it.
+ * The planes stay valid until the next nova_hip_denoise_read with a larger frame or nova_hip_shutdown.  OIDN
+ * itself is not part of this library (its binary is absent from the reference tree).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  float* color;  /* HOST pointers, width * height * 3 floats each, row-major, x y z per pixel */
+  float* albedo;
+  float* normal;
+  float* output; /* to be filled by the denoiser before nova_hip_denoise_write */
+} nova_hip_denoise_planes;
+int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* albedo, const nova_hip_image* normal,
+                          uint32_t width, uint32_t height, nova_hip_denoise_planes* planes);
+int nova_hip_denoise_write(nova_hip_image* color, uint32_t width, uint32_t height);
+
+/* ---------------------------------------------------------------------------------------------
  * Tile stacks for the multi-GPU gather.  No counterpart in the reference (one device,
  * src/backend/opencl/accelerator/accelerator.cpp:11-25); SURVEY.md §8e.  A frame is cut into 64x64 tiles,
  * tile t belongs to rank t % ranks.  nova_hip_tiles_pack writes rank's tiles of a float4 or uchar4 image

@@ -85,6 +85,17 @@ inline void render_samples(const SceneParams& scene_params, const std::vector<ui
     reinterpret_cast<const nova_area_light*>(lights), num_lights, materials, sky, denoise_available));
 }
 
+// Extension: the device half of the denoise hand-off (src/core/raytracer.cpp:211-242) — include/nova_hip.h,
+// nova_hip_denoise_read / nova_hip_denoise_write.  The planes are pinned host memory the library owns.
+inline nova_hip_denoise_planes denoise_read(ImageHandle color, ImageHandle albedo, ImageHandle normal, uint2 pixel_dims) {
+  nova_hip_denoise_planes planes {};
+  HIP_CHECK_AND_THROW(nova_hip_denoise_read(color, albedo, normal, pixel_dims.x, pixel_dims.y, &planes));
+  return planes;
+}
+inline void denoise_write(ImageHandle color, uint2 pixel_dims) {
+  HIP_CHECK_AND_THROW(nova_hip_denoise_write(color, pixel_dims.x, pixel_dims.y));
+}
+
 }
 
 #endif // HIP_ENTRY_HPP

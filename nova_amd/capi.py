@@ -31,6 +31,7 @@ EXPORTS = [
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
     "nova_hip_tiles_stack_bytes", "nova_hip_tiles_pack", "nova_hip_tiles_unpack",
+    "nova_hip_denoise_read", "nova_hip_denoise_write",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE, E_NOT_CACHED = -1, -2, -3, -4, -5, -6
@@ -111,6 +112,8 @@ def load() -> ctypes.CDLL:
         "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_build_bvh_device": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_validate_scene_pack": [vp, vp, vp],
+        "nova_hip_denoise_read": [vp, vp, vp, u32, u32, vp],
+        "nova_hip_denoise_write": [vp, u32, u32],
         "nova_hip_tiles_pack": [vp, u32, u32, vp],
         "nova_hip_tiles_unpack": [vp, u32, vp],
     }
@@ -327,6 +330,25 @@ def trace_rays_noalloc(triangles: Buffer, bvh: Buffer, point_tmax: Buffer, dir_f
     """nova_hip_trace_rays_noalloc: the same, for callers that cannot allocate (include/nova_hip.h)."""
     check(load().nova_hip_trace_rays_noalloc(triangles.ptr, bvh.ptr, point_tmax.ptr, dir_flags.ptr,
                                              hits.ptr, num_rays))
+
+
+class DenoisePlanes(ctypes.Structure):
+    _fields_ = [(n, ctypes.POINTER(ctypes.c_float)) for n in ("color", "albedo", "normal", "output")]
+
+
+def denoise_read(color: Image, albedo: Image, normal: Image):
+    """nova_hip_denoise_read: returns four numpy views [h, w, 3] of the library's pinned host planes
+    (color, albedo, normal, output) — what the reference hands to its denoiser (raytracer.cpp:216-227)."""
+    planes = DenoisePlanes()
+    check(load().nova_hip_denoise_read(color.handle, albedo.handle, normal.handle, color.width, color.height,
+                                       ctypes.byref(planes)))
+    shape = (color.height, color.width, 3)
+    return tuple(np.ctypeslib.as_array(getattr(planes, n), shape=shape) for n in ("color", "albedo", "normal", "output"))
+
+
+def denoise_write(color: Image):
+    """nova_hip_denoise_write: the `output` plane back into the image (pack + write_image2D, raytracer.cpp:240-241)."""
+    check(load().nova_hip_denoise_write(color.handle, color.width, color.height))
 
 
 def tiles_stack_bytes(width: int, height: int, ranks: int, texel_bytes: int) -> int:

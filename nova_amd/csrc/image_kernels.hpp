@@ -193,6 +193,43 @@ __global__ __launch_bounds__(256) void k_post_process(PostArgs A) {
   }
 }
 
+// Denoise hand-off (src/core/raytracer.cpp:211-242): flatten<float4, float, 3> and pack<float4, float, 3>
+// (src/vector/vector_utils.hpp:8-51) on the device.  Four pixels per thread: 64 bytes in, 48 bytes out as three
+// aligned 16-byte stores (and the reverse), the remainder of a plane pixel by pixel.
+__global__ __launch_bounds__(256) void k_flatten3(const float4* __restrict__ in, float* __restrict__ out, uint32_t n_pixels) {
+  const uint32_t quads = n_pixels / 4u;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+    const float4 a = in[4u * q], b = in[4u * q + 1u], c = in[4u * q + 2u], d = in[4u * q + 3u];
+    float4* o = reinterpret_cast<float4*>(out) + 3u * static_cast<size_t>(q);
+    o[0] = make_float4(a.x, a.y, a.z, b.x);
+    o[1] = make_float4(b.y, b.z, c.x, c.y);
+    o[2] = make_float4(c.z, d.x, d.y, d.z);
+  }
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_pixels - 4u * quads) {
+    const uint32_t i = 4u * quads + t;
+    const float4 a = in[i];
+    out[3u * static_cast<size_t>(i)] = a.x; out[3u * static_cast<size_t>(i) + 1u] = a.y; out[3u * static_cast<size_t>(i) + 2u] = a.z;
+  }
+}
+// w = 0: pack's vector is value-initialised and only x, y, z are assigned (vector_utils.hpp:35-47)
+__global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ in, float4* __restrict__ out, uint32_t n_pixels) {
+  const uint32_t quads = n_pixels / 4u;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+    const float4* s = reinterpret_cast<const float4*>(in) + 3u * static_cast<size_t>(q);
+    const float4 a = s[0], b = s[1], c = s[2];
+    out[4u * q] = make_float4(a.x, a.y, a.z, 0.0f);
+    out[4u * q + 1u] = make_float4(a.w, b.x, b.y, 0.0f);
+    out[4u * q + 2u] = make_float4(b.z, b.w, c.x, 0.0f);
+    out[4u * q + 3u] = make_float4(c.y, c.z, c.w, 0.0f);
+  }
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_pixels - 4u * quads) {
+    const uint32_t i = 4u * quads + t;
+    out[i] = make_float4(in[3u * static_cast<size_t>(i)], in[3u * static_cast<size_t>(i) + 1u], in[3u * static_cast<size_t>(i) + 2u], 0.0f);
+  }
+}
+
 // Tile stacks for the multi-GPU gather: rank r's tiles (tile id = r + k * ranks, 64x64 texels each, zero
 // beyond the image border and beyond the last tile) as one contiguous [k][64][64] array, and back.
 template <typename T>

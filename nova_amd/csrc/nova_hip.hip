@@ -145,6 +145,10 @@ struct Ctx {
   uint32_t* d_spill = nullptr;           // traversal stack entries beyond the LDS part
   size_t spill_words = 0;
   TilePlan plan;
+  // denoise hand-off: four float3 planes (colour, albedo, normal, output) on the device and pinned on the host
+  float* d_denoise = nullptr;
+  float* h_denoise = nullptr;
+  size_t denoise_pixels = 0;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -927,6 +931,8 @@ int nova_hip_shutdown(void) {
   for (auto& s : g.scenes) free_scene(s);
   g.scenes.clear();
   free_tile_plan();
+  (void) hipFree(g.d_denoise);
+  (void) hipHostFree(g.h_denoise);
   free_frame_buffers(g.fb);
   (void) hipFree(g.d_spill);
   (void) hipFree(g.d_queues);
@@ -1639,6 +1645,73 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
   wait_all(); // the other lanes are done already: their last kernels were waited for by this one's
   collect_events();
   return rc;
+}
+
+// ---- denoise hand-off ---------------------------------------------------------------------------
+static int ensure_denoise_planes(size_t pixels) {
+  if (g.denoise_pixels >= pixels) return 0;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  (void) hipFree(g.d_denoise);
+  (void) hipHostFree(g.h_denoise);
+  g.d_denoise = g.h_denoise = nullptr;
+  g.denoise_pixels = 0;
+  const size_t bytes = 4 * pixels * 3 * sizeof(float);
+  HIP_TRY(hipMalloc(&g.d_denoise, bytes));
+  hipError_t e = hipHostMalloc(&g.h_denoise, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { (void) hipFree(g.d_denoise); g.d_denoise = nullptr; return static_cast<int>(e); }
+  g.denoise_pixels = pixels;
+  return 0;
+}
+
+int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* albedo, const nova_hip_image* normal,
+                          uint32_t width, uint32_t height, nova_hip_denoise_planes* planes) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!planes || width == 0 || height == 0 || !float_image_ok(color, width, height) ||
+      !float_image_ok(albedo, width, height) || !float_image_ok(normal, width, height))
+    return NOVA_HIP_E_INVALID_ARGUMENT;
+  const size_t pixels = static_cast<size_t>(width) * height;
+  if (pixels >= (1ull << 32)) return NOVA_HIP_E_TOO_LARGE;
+  rc = ensure_denoise_planes(pixels);
+  if (rc) return rc;
+  const size_t stride = g.denoise_pixels * 3; // floats per plane slot (slots sized for the largest frame seen)
+  const nova_hip_image* src[3] = { color, albedo, normal };
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((pixels / 4 + 255) / 256 + 1, static_cast<size_t>(g.num_cus) * 8));
+  for (int k = 0; k < 3; k++)
+    hipLaunchKernelGGL(k_flatten3, dim3(blocks), dim3(256), 0, g.stream, static_cast<const float4*>(src[k]->data),
+                       g.d_denoise + k * stride, static_cast<uint32_t>(pixels));
+  HIP_TRY(hipGetLastError());
+  // one copy for the three planes when they are adjacent (the usual case: the slots fit the frame exactly)
+  if (g.denoise_pixels == pixels) {
+    HIP_TRY(hipMemcpyAsync(g.h_denoise, g.d_denoise, 3 * stride * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+  } else {
+    for (int k = 0; k < 3; k++)
+      HIP_TRY(hipMemcpyAsync(g.h_denoise + k * stride, g.d_denoise + k * stride, pixels * 3 * sizeof(float),
+                             hipMemcpyDeviceToHost, g.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  planes->color = g.h_denoise;
+  planes->albedo = g.h_denoise + stride;
+  planes->normal = g.h_denoise + 2 * stride;
+  planes->output = g.h_denoise + 3 * stride;
+  return 0;
+}
+
+int nova_hip_denoise_write(nova_hip_image* color, uint32_t width, uint32_t height) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (width == 0 || height == 0 || !float_image_ok(color, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const size_t pixels = static_cast<size_t>(width) * height;
+  if (g.denoise_pixels < pixels || !g.h_denoise) return NOVA_HIP_E_INVALID_ARGUMENT; // nova_hip_denoise_read comes first
+  const size_t stride = g.denoise_pixels * 3;
+  HIP_TRY(hipMemcpyAsync(g.d_denoise + 3 * stride, g.h_denoise + 3 * stride, pixels * 3 * sizeof(float),
+                         hipMemcpyHostToDevice, g.stream));
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((pixels / 4 + 255) / 256 + 1, static_cast<size_t>(g.num_cus) * 8));
+  hipLaunchKernelGGL(k_pack3, dim3(blocks), dim3(256), 0, g.stream, g.d_denoise + 3 * stride,
+                     static_cast<float4*>(color->data), static_cast<uint32_t>(pixels));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
 }
 
 // ---- tile stacks for the multi-GPU gather ------------------------------------------------------
