@@ -35,8 +35,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # 256 CUs x 128 FP32 FMA lanes x 2 flop x 2.4 GHz
+WAVE_ISSUE_PEAK = 256 * 4 * 2.4e9  # wave-instructions per second the chip can issue on one port: 1 / SIMD / cycle
 SEED = 1
 MAX_DEPTH = 5  # primary segment + 4 bounces
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline_and_work(scene_mod, oracle, sc, params, width, height, time_seed):
@@ -75,6 +87,7 @@ def cpu_baseline_and_work(scene_mod, oracle, sc, params, width, height, time_see
     n_tri_cam = float(cam[5]) / int(cam[0])
     base = {
         "value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model(), "nproc": os.cpu_count(),
         "sample": f"{spp} spp of the whole {width}x{height} frame, max_depth {MAX_DEPTH}: {rays} rays in "
                   f"{dt:.2f} s, reference-order traversal (kernels/raytrace.hpp:38-102), OpenMP",
     }
@@ -265,26 +278,59 @@ def main():
             achieved = bytes_per_launch / avg_launch_s / 1e9
             cam_bytes = 32.0 * n_node_cam + 48.0 * n_tri_cam + 64.0
             cam_s = k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])) / 1e3
+            rates = capi.measure_device()  # measured denominators
+            rays_per_s = rays_k / launches / avg_launch_s
+            valu_ops_per_ray = 17.0 * n_node + 33.0 * n_tri
+            valu_rate_measured = rates["fp32_fma_tflops"] * 1e12 / 2.0  # one fma = one VALU lane-op
             roof.update({
                 "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
                 "n_node_per_ray": round(n_node, 2), "n_tri_per_ray": round(n_tri, 2),
                 "rays_per_launch": round(rays_k / launches, 1),
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                "valu_ops_per_ray": round(17.0 * n_node + 33.0 * n_tri, 1),
-                "camera_ray_kernel": {
-                    "kernel": "k_traverse_packet", "algorithmic_bytes_per_ray": round(cam_bytes, 1),
-                    "avg_launch_ms": round(cam_s * 1e3, 4),
-                    "achieved": round(cam_bytes * int(local[0]) / max(1, int(k["camera_traverse_launches"])) / max(cam_s, 1e-12) / 1e9, 1),
-                },
+                "valu_ops_per_ray": round(valu_ops_per_ray, 1),
+                "measured": {"hbm_copy_gbs": round(rates["hbm_copy_gbs"], 1),
+                             "fp32_fma_tflops": round(rates["fp32_fma_tflops"], 2),
+                             "how": "nova_hip_measure_device: 1 GiB float4 copy (read + write bytes), loop of independent v_fma_f32"},
+                "frac_of_measured_copy": round(achieved / rates["hbm_copy_gbs"], 4),
+                # the VALU side of SURVEY §8d's max(...): algorithmic slab / Woop lane-ops against the FP32 vector rate
+                "valu_frac": round(valu_ops_per_ray * rays_per_s / (FP32_VECTOR_PEAK_TFLOPS * 1e12 / 2.0), 4),
+                "valu_frac_of_measured": round(valu_ops_per_ray * rays_per_s / valu_rate_measured, 4),
             })
+            # what the counters say (profiles/, rocprofv3 passes of scripts/prof_run.py on the same frame)
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    roof["traffic"] = pj.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)"
+                    if roof["traffic"]:
+                        # HBM-side bytes per second while the kernel runs: how busy HBM really is.  Far below `frac`
+                        # because the scene (51 MB) is served by L1 / L2 / Infinity Cache, not by HBM
+                        roof["hbm_frac_counter"] = round(roof["traffic"] / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+                    if pj.get("valu_wave_insts_per_launch"):
+                        wi = pj["valu_wave_insts_per_launch"]
+                        roof["valu_issue_frac_counter"] = round(wi / avg_launch_s / WAVE_ISSUE_PEAK, 4)
+                        roof["valu_lane_ops_per_ray_counter"] = round(pj.get("valu_thread_cycles_per_launch", 0) / max(1.0, rays_k / launches), 1)
+                    cam_pj = pj.get("camera_ray_kernel")
                 except Exception:
-                    pass
+                    cam_pj = None
+            else:
+                cam_pj = None
+            # camera rays: the packet kernel fetches a node once per 64 rays through the scalar cache, so a
+            # per-ray byte model says nothing about it; it is bound by instruction issue (VALU + SALU ports)
+            cam_s = k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])) / 1e3
+            cam = {"kernel": "k_traverse_packet", "avg_launch_ms": round(cam_s * 1e3, 4),
+                   "rays_per_launch": int(local[0]) // max(1, int(k["camera_traverse_launches"])),
+                   "bound": "instruction issue (wave-uniform node and triangle fetches through the scalar cache)",
+                   "algorithmic_valu_frac": round((17.0 * n_node_cam + 33.0 * n_tri_cam) * int(local[0]) /
+                                                  max(1, int(k["camera_traverse_launches"])) / max(cam_s, 1e-12) /
+                                                  (FP32_VECTOR_PEAK_TFLOPS * 1e12 / 2.0), 4),
+                   "n_node_per_ray": round(n_node_cam, 2), "n_tri_per_ray": round(n_tri_cam, 2)}
+            if cam_pj and cam_pj.get("valu_wave_insts_per_launch"):
+                cam["issue_frac_valu_counter"] = round(cam_pj["valu_wave_insts_per_launch"] / cam_s / WAVE_ISSUE_PEAK, 4)
+                cam["issue_frac_salu_counter"] = round(cam_pj.get("salu_wave_insts_per_launch", 0) / cam_s / WAVE_ISSUE_PEAK, 4)
+            roof["camera_ray_kernel"] = cam
         else:
             out["cpu_baseline"] = None
         out["roofline"] = roof

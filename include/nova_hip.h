@@ -339,6 +339,14 @@ typedef struct {
   uint64_t camera_traverse_launches; /* launches (first path segments), which run their own kernel */
 } nova_hip_counters;
 int nova_hip_get_counters(nova_hip_counters* out);
+/* Roofline denominators measured on the device the library runs on (no counterpart in the reference;
+ * SURVEY.md §8d): bytes read + written per second by a 1 GiB float4 copy kernel, and the FP32 rate of a
+ * loop of independent fused multiply-adds (2 flop each).  Takes a few milliseconds and 2 GiB for its duration. */
+typedef struct {
+  double hbm_copy_gbs;
+  double fp32_fma_tflops;
+} nova_hip_device_rates;
+int nova_hip_measure_device(nova_hip_device_rates* out);
 int nova_hip_reset_counters(void);
 
 /* ---------------------------------------------------------------------------------------------

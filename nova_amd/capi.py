@@ -31,7 +31,7 @@ EXPORTS = [
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
     "nova_hip_tiles_stack_bytes", "nova_hip_tiles_pack", "nova_hip_tiles_unpack",
-    "nova_hip_denoise_read", "nova_hip_denoise_write",
+    "nova_hip_denoise_read", "nova_hip_denoise_write", "nova_hip_measure_device",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE, E_NOT_CACHED = -1, -2, -3, -4, -5, -6
@@ -112,6 +112,7 @@ def load() -> ctypes.CDLL:
         "nova_hip_build_bvh": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_build_bvh_device": [vp, u64, vp, u64, vp, vp, vp, vp],
         "nova_hip_validate_scene_pack": [vp, vp, vp],
+        "nova_hip_measure_device": [vp],
         "nova_hip_denoise_read": [vp, vp, vp, u32, u32, vp],
         "nova_hip_denoise_write": [vp, u32, u32],
         "nova_hip_tiles_pack": [vp, u32, u32, vp],
@@ -164,6 +165,17 @@ def counters() -> dict:
     c = Counters()
     check(load().nova_hip_get_counters(ctypes.byref(c)))
     return c.as_dict()
+
+
+class DeviceRates(ctypes.Structure):
+    _fields_ = [("hbm_copy_gbs", ctypes.c_double), ("fp32_fma_tflops", ctypes.c_double)]
+
+
+def measure_device() -> dict:
+    """nova_hip_measure_device: the roofline's measured denominators (float4 copy GB/s, FP32 FMA TFLOP/s)."""
+    r = DeviceRates()
+    check(load().nova_hip_measure_device(ctypes.byref(r)))
+    return {"hbm_copy_gbs": r.hbm_copy_gbs, "fp32_fma_tflops": r.fp32_fma_tflops}
 
 
 def reset_counters():

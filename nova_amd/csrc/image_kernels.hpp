@@ -264,6 +264,31 @@ __global__ __launch_bounds__(256) void k_tiles_unpack(T* image, uint32_t width, 
   }
 }
 
+// Denominators of the roofline, measured on the box: a float4 copy (HBM read + write) and a
+// loop of independent v_fma_f32 chains (FP32 vector rate).
+__global__ __launch_bounds__(256) void k_measure_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  // four independent 16-byte loads in flight per lane, a block's 4 KiB pieces next to each other
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4u;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) * 4u + threadIdx.x; i + 3u * blockDim.x < n; i += stride) {
+    const float4 a = src[i], b = src[i + blockDim.x], c = src[i + 2u * blockDim.x], d = src[i + 3u * blockDim.x];
+    dst[i] = a; dst[i + blockDim.x] = b; dst[i + 2u * blockDim.x] = c; dst[i + 3u * blockDim.x] = d;
+  }
+}
+__global__ __launch_bounds__(256) void k_measure_fma(float* out, int iterations, float seed) {
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = seed + static_cast<float>(threadIdx.x + k);
+  const float m = 0.999f, c = 0.001f;
+  for (int i = 0; i < iterations; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = fma_(a[k], m, c);
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) s += a[k];
+  if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s; // keeps the chains alive, never true in practice
+}
+
 // dst[i] = pattern (1..16 bytes), for Buffer::fill / fill_image2D
 template <typename T>
 __global__ void k_fill(T* dst, T value, size_t count) {

@@ -1647,6 +1647,48 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
   return rc;
 }
 
+// ---- roofline denominators -----------------------------------------------------------------------
+int nova_hip_measure_device(nova_hip_device_rates* out) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!out) return NOVA_HIP_E_INVALID_ARGUMENT;
+  const size_t n = (static_cast<size_t>(1) << 30) / sizeof(float4); // 1 GiB read + 1 GiB written per pass
+  float4 *src = nullptr, *dst = nullptr;
+  HIP_TRY(hipMalloc(&src, n * sizeof(float4)));
+  hipError_t e = hipMalloc(&dst, n * sizeof(float4));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e == hipSuccess) e = hipMemsetAsync(src, 0, n * sizeof(float4), g.stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float best_copy = 1e30f, best_fma = 1e30f;
+  const int iterations = 4096;
+  const unsigned fma_blocks = static_cast<unsigned>(g.num_cus) * 32u;
+  for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {
+    (void) hipEventRecord(e0, g.stream);
+    hipLaunchKernelGGL(k_measure_copy, dim3(static_cast<unsigned>(g.num_cus) * 32u), dim3(256), 0, g.stream, src, dst, n);
+    (void) hipEventRecord(e1, g.stream);
+    e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best_copy) best_copy = ms;
+    if (e != hipSuccess) break;
+    (void) hipEventRecord(e0, g.stream);
+    hipLaunchKernelGGL(k_measure_fma, dim3(fma_blocks), dim3(256), 0, g.stream, reinterpret_cast<float*>(dst), iterations, 1.0f + rep);
+    (void) hipEventRecord(e1, g.stream);
+    e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best_fma) best_fma = ms;
+  }
+  if (e0) (void) hipEventDestroy(e0);
+  if (e1) (void) hipEventDestroy(e1);
+  (void) hipFree(src);
+  (void) hipFree(dst);
+  if (e != hipSuccess) return static_cast<int>(e);
+  out->hbm_copy_gbs = 2.0 * static_cast<double>(n) * sizeof(float4) / (best_copy * 1e-3) / 1e9;
+  out->fp32_fma_tflops = 2.0 * 8.0 * iterations * static_cast<double>(fma_blocks) * 256.0 / (best_fma * 1e-3) / 1e12;
+  return 0;
+}
+
 // ---- denoise hand-off ---------------------------------------------------------------------------
 static int ensure_denoise_planes(size_t pixels) {
   if (g.denoise_pixels >= pixels) return 0;

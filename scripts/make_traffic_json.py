@@ -10,13 +10,26 @@ tot = collections.defaultdict(float)
 cnt = collections.defaultdict(int)
 for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if kernel in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if kernel in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU",
+                                                                    "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD"):
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[row["Counter_Name"]] += 1
+        if "k_traverse_packet" in row["Kernel_Name"] and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM"):
+            tot["cam_" + row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt["cam_" + row["Counter_Name"]] += 1
 fetch = tot["FETCH_SIZE"] * 1024 / max(1, cnt["FETCH_SIZE"])
 write = tot["WRITE_SIZE"] * 1024 / max(1, cnt["WRITE_SIZE"])
+def per(name):
+    return round(tot[name] / cnt[name]) if cnt[name] else None
+
+
 json.dump({
     "kernel": kernel, "dispatches": cnt["FETCH_SIZE"],
+    "valu_wave_insts_per_launch": per("SQ_INSTS_VALU"), "valu_thread_cycles_per_launch": per("SQ_THREAD_CYCLES_VALU"),
+    "vmem_read_wave_insts_per_launch": per("SQ_INSTS_VMEM_RD"),
+    "camera_ray_kernel": {"valu_wave_insts_per_launch": per("cam_SQ_INSTS_VALU"),
+                          "salu_wave_insts_per_launch": per("cam_SQ_INSTS_SALU"),
+                          "smem_wave_insts_per_launch": per("cam_SQ_INSTS_SMEM")},
     "fetch_bytes_per_launch_raw": round(fetch), "write_bytes_per_launch": round(write),
     "hbm_bytes_per_launch": round(2 * fetch + write),
     "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads; an upper bound "
