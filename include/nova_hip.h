@@ -176,6 +176,11 @@ int nova_hip_image_fill(nova_hip_image* image, const void* texel);
  * backend's own 64-byte node layout on first use and cached until a buffer is freed or rewritten.
  * `albedo_feature*`/`normal_feature*` may be NULL when denoise_available == 0 and `lights` may be
  * NULL when num_lights == 0 (src/core/raytracer.cpp:81-100, :129-132).
+ * `materials` is the reference's float4 layered array, or (the texture path,
+ * src/material/material_loader.cpp:39-80) a uchar4 one (texel_bytes == 4) holding the layers as
+ * MaterialLoader has them BEFORE its last step: the uint8 -> float conversion x / 255.0f (:69-76) then happens
+ * at sampling time on the device, with the same correctly rounded division, so every sampled value — and the
+ * frame — is bit-identical while the array takes a quarter of the bytes and of the texture-gather traffic.
  * ------------------------------------------------------------------------------------------- */
 int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time,
                              nova_hip_image* temp_color1, uint32_t width, uint32_t height,

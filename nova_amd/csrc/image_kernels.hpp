@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumulateArgs A) {
     const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
     const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
     auto ld = [&](const float4* p) {
-      return A.mask ? sample_kept(p, A.mask, w, h, u, v) : sample_linear<false>(ImageView { p, w, h, 1 }, u, v, 0);
+      return A.mask ? sample_kept(p, A.mask, w, h, u, v) : sample_linear<false>(ImageView { p, w, h, 1, nullptr, nullptr }, u, v, 0);
     };
     V3 c = ld(A.color1);
     V3 a { 0.f, 0.f, 0.f }, n { 0.f, 0.f, 0.f };

@@ -1242,7 +1242,8 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   if (!float_image_ok(temp_color1, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (denoise_available && (!float_image_ok(albedo_feature1, width, height) || !float_image_ok(normal_feature1, width, height)))
     return NOVA_HIP_E_INVALID_ARGUMENT;
-  if (!materials || !materials->data || materials->texel_bytes != 16 || !sky || !sky->data || sky->texel_bytes != 16)
+  if (!materials || !materials->data || (materials->texel_bytes != 16 && materials->texel_bytes != 4) || !sky ||
+      !sky->data || sky->texel_bytes != 16)
     return NOVA_HIP_E_INVALID_ARGUMENT;
   if (num_lights > 0 && !lights) return NOVA_HIP_E_INVALID_ARGUMENT;
   const Alloc* am = find_alloc(tri_meta);
@@ -1290,8 +1291,10 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   F.lights = lights;
   F.num_lights = num_lights;
   F.materials = { static_cast<const float4*>(materials->data), static_cast<int>(materials->width),
-                  static_cast<int>(materials->height), static_cast<int>(materials->layers) };
-  F.sky = { static_cast<const float4*>(sky->data), static_cast<int>(sky->width), static_cast<int>(sky->height), 1 };
+                  static_cast<int>(materials->height), static_cast<int>(materials->layers),
+                  materials->texel_bytes == 4 ? static_cast<const uchar4*>(materials->data) : nullptr, nullptr };
+  F.sky = { static_cast<const float4*>(sky->data), static_cast<int>(sky->width), static_cast<int>(sky->height), 1,
+            nullptr, nullptr };
   F.denoise = denoise_available ? 1u : 0u;
   F.out_color = static_cast<float4*>(temp_color1->data);
   F.out_albedo = denoise_available ? static_cast<float4*>(albedo_feature1->data) : nullptr;
@@ -1446,7 +1449,8 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
   if (!pixels || !pixels->data || pixels->texel_bytes != 4 || pixels->width != width || pixels->height != height)
     return NOVA_HIP_E_INVALID_ARGUMENT;
   PostArgs A;
-  A.color2 = { static_cast<const float4*>(temp_color2->data), static_cast<int>(width), static_cast<int>(height), 1 };
+  A.color2 = { static_cast<const float4*>(temp_color2->data), static_cast<int>(width), static_cast<int>(height), 1,
+               nullptr, nullptr };
   A.pixels = static_cast<uchar4*>(pixels->data);
   A.width = width;
   A.height = height;

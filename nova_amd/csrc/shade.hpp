@@ -22,6 +22,12 @@ namespace nova_hip {
 struct ImageView {
   const float4* texels;
   int w, h, layers;
+  // 8-bit storage: when set, the image is uchar4 texels and texel value = u8 / 255.0f,
+  // the very conversion MaterialLoader::build applies on the host before upload (src/material/
+  // material_loader.cpp:69-76) — so the sampled values are bit-identical and the array is a quarter of the bytes.
+  // lut[x] = float(x) / 255.0f (k_shade fills it in LDS with the same correctly rounded division).
+  const uchar4* u8;
+  const float* lut;
 };
 
 struct PathPlanes {
@@ -69,7 +75,12 @@ constexpr uint32_t kShadeBlock = 1024; // one compaction atomic per 1024 paths
 // what the reference's float-coordinate samplers are (kernels/backend/opencl/image.hpp:14-21).
 NV_DEV float4 texel(const ImageView& im, int i, int j, int layer) {
   if (i < 0 || j < 0 || i >= im.w || j >= im.h) return make_float4(0.f, 0.f, 0.f, 0.f);
-  return im.texels[(static_cast<size_t>(layer) * im.h + j) * im.w + i];
+  const size_t k = (static_cast<size_t>(layer) * im.h + j) * im.w + i;
+  if (im.u8) {
+    const uchar4 t = im.u8[k];
+    return make_float4(im.lut[t.x], im.lut[t.y], im.lut[t.z], im.lut[t.w]);
+  }
+  return im.texels[k];
 }
 template <bool REPEAT>
 NV_DEV V3 sample_linear(const ImageView& im, float s, float t, int layer) {
@@ -308,6 +319,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_in = F.n_active[it];
   const uint32_t P = F.stride;
+  __shared__ float s_u8_lut[256];
+  if (F.materials.u8) { // uniform over the launch
+    if (threadIdx.x < 256) s_u8_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
+    __syncthreads();
+    F.materials.lut = s_u8_lut;
+  }
   bool alive = false;
   bool emit_shadow = false, emit_mis = false, emit_cont = false, shaded = false;
 

@@ -34,7 +34,7 @@ class Raytracer:
         self.fixed_seed: Optional[int] = None
 
     # raytracer.cpp:47-167
-    def set_scene(self, scene: Scene, params: np.ndarray, width: int, height: int):
+    def set_scene(self, scene: Scene, params: np.ndarray, width: int, height: int, materials_u8=None):
         self.params = np.ascontiguousarray(params)
         if (width, height) != (self.width, self.height):
             f4 = dict(texel_bytes=16, address_mode=capi.ADDRESS_CLAMP, filter_mode=capi.FILTER_LINEAR)
@@ -54,8 +54,11 @@ class Raytracer:
         self.bvh_buf = capi.Buffer(scene.bvh)
         self.light_buf = capi.Buffer(scene.lights) if scene.num_lights else None
         self.num_lights = scene.num_lights
-        m = scene.materials
-        self.material_imgs = capi.Image(m.shape[2], m.shape[1], layers=m.shape[0], texel_bytes=16,
+        # float4 layers as MaterialLoader::build returns them, or its uint8 layers (8-bit storage: the backend
+        # converts x / 255.0f at sampling time, include/nova_hip.h)
+        m = scene.materials if materials_u8 is None else np.ascontiguousarray(materials_u8, np.uint8)
+        self.material_imgs = capi.Image(m.shape[2], m.shape[1], layers=m.shape[0],
+                                        texel_bytes=16 if materials_u8 is None else 4,
                                         address_mode=capi.ADDRESS_WRAP, data=m)
         s = scene.sky
         self.sky_img = capi.Image(s.shape[1], s.shape[0], texel_bytes=16,

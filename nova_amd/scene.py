@@ -402,6 +402,11 @@ def load_obj(path: str):
     return verts, meta, em, [tm, mats]
 
 
+def aircraft_layers_u8() -> np.ndarray:
+    """The aircraft's material layers as uint8 [layers, h, w, 4] (what MaterialLoader holds before x / 255)."""
+    return np.load(os.path.join(_HERE, "..", "tests", "golden", "aircraft.npz"))["layers"]
+
+
 def aircraft_scene(sky_size=(1024, 512)) -> Scene:
     """BASELINE config 5 on its own asset, from the committed data fixture tests/golden/aircraft.npz
     (tests/golden/make_aircraft_fixture.py: assets/aircraft/aircraft.obj + the two JPEGs its MTL uses that

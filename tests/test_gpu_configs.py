@@ -144,3 +144,35 @@ def test_c5_aircraft_textures_normal_maps_and_sky():
     n_ref = ref[2][..., :3]
     on_model = np.abs(np.linalg.norm(n_ref, axis=-1) - 1.0) < 1e-3
     assert 0.1 < on_model.mean() < 0.95
+
+
+def test_c5_eight_bit_material_layers_give_the_same_frame_bit_for_bit():
+    """SURVEY §8f rank 4 (texture path): the layers uploaded as uchar4 (a quarter of the bytes) and converted
+    x / 255.0f at sampling time give exactly the frame of the reference's float4 array — and the oracle's."""
+    sc = S.aircraft_scene()
+    u8 = S.aircraft_layers_u8()
+    assert (sc.materials == (u8.astype(np.float32) / np.float32(255.0))).all()
+    w, h = 512, 288
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.AIRCRAFT_CAMERA), shading_metallic=0.6, shading_roughness=0.3)
+    capi.set_option(capi.OPT_MAX_DEPTH, 5)
+    out = []
+    for layers in (None, u8):
+        rt = Raytracer(0, denoise_available=True)
+        rt.set_scene(sc, p, w, h, materials_u8=layers)
+        rt.kernel_raytrace(11)
+        out.append([im.read() for im in (rt.temp_color_img1, rt.albedo_img1, rt.normal_img1)])
+    for a, b in zip(*out):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    ref = oracle().kernel_raytrace(sc, p, 11, w, h, denoise_available=1, max_depth=5)
+    for got, r in zip(out[1], ref):
+        assert rel_rmse(got, r) <= RADIANCE_TOL
+        assert (got.view(np.uint32) == r.view(np.uint32)).all(-1).mean() > 0.999
+    # a uchar4 array of the wrong texel size is still refused elsewhere: the sky stays float4
+    lib = capi.load()
+    rt8 = Raytracer(0)
+    rt8.set_scene(sc, p, w, h, materials_u8=u8)
+    sky8 = capi.Image(8, 4, texel_bytes=4)
+    rc = lib.nova_hip_launch_raytrace(np.ascontiguousarray(p).ctypes.data, 1, rt8.temp_color_img1.handle, w, h,
+                                      rt8.triangle_buf.ptr, rt8.tri_meta_buf.ptr, rt8.bvh_buf.ptr, None, 0,
+                                      rt8.material_imgs.handle, sky8.handle, 0, None, None)
+    assert rc == capi.E_INVALID_ARGUMENT
