@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -269,12 +270,14 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const uint32_t* __res
 
 // ---- one level ----------------------------------------------------------------------------------------
 // flag[i] = 1 when node ls + i is to be split at this level (bvh.cpp:137-148)
-__global__ void k_level_flags(const BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
+// `small` = largest node (in triangles) left to k_subtree at this depth, 0 = none
+__global__ void k_level_flags(const BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t small,
                               uint32_t* __restrict__ flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const BNode& nd = nodes[ls + i];
-  flag[i] = (nd.end - nd.begin > kMinTrianglesPerLeaf) ? 1u : 0u;
+  const uint32_t cnt = nd.end - nd.begin;
+  flag[i] = (cnt > kMinTrianglesPerLeaf && cnt > small) ? 1u : 0u;
 }
 
 __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, const uint32_t* __restrict__ flag,
@@ -384,7 +387,20 @@ __device__ __forceinline__ void best_step(float& key, uint32_t& idx) {
 
 // `load(b)` returns bin b (b < num_bins).  rb: 6 * num_bins floats of LDS, rb[j * num_bins + b].
 // All 64 lanes of the wave call this; lane 0 writes *out.
-template <class Load>
+// LDS written by a wave and read back by the same wave: a block barrier when the block is that one wave
+// (k_bin_sah, k_sah_multi), else the wave's own in-order LDS queue plus a compiler fence (k_subtree)
+template <bool BLOCK>
+__device__ __forceinline__ void wave_lds_sync() {
+  if (BLOCK) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <class Load, bool BLOCK = true>
 __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis, Load load, float* rb, AxisBest* out) {
   const int lane = static_cast<int>(threadIdx.x & 63u);
   const uint32_t chunks = (num_bins + 63) / 64;
@@ -402,7 +418,7 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
       }
     carry = last_lane(v);
   }
-  __syncthreads(); // the block is this one wave: its LDS writes above are visible to its reads below
+  wave_lds_sync<BLOCK>(); // the wave's LDS writes above are visible to its reads below
   // left_bounds[s] = box of bins 0 .. s; every split s < num_bins - 1 in its own lane
   bool has = false;
   float best_cost = kFltMax;
@@ -769,6 +785,357 @@ __global__ void k_scatter(const uint32_t* __restrict__ order, const uint32_t* __
   node_of_out[pos] = owner;
 }
 
+// ---- small subtrees: one work-group finishes the whole subtree of a node ----------------------------------
+// Level-synchronous construction pays ~20 dependent launches and a host wait per level, and from depth ~10 on
+// the levels are millions of tiny nodes.  A node of at most kSmallTris triangles at depth >= kSmallMinDepth (so
+// that a wave's bins fit LDS) is therefore taken out of the level loop ("small root") and k_subtree builds its
+// whole subtree in one work-group: the triangle order of its segment lives in LDS (ping-pong), each wave takes
+// a node of the current local level — bins, split evaluation (wave_sah), choice, child records, stable split —
+// and the work-group meets once per local level.  Same arithmetic, same decisions, same tree.  Nodes are
+// written to a per-root region of a temporary array with local ids (level by level); k_subtree_place then moves
+// them to their final ids: "stage" l of the final array holds the nodes of local level l of every root, so that
+// the stage list (top levels, then local levels 1, 2, ...) is still a layering with parents before children,
+// which is all the later passes (sizes, flattening, bvh_pack_device.hpp) need of "levels".
+constexpr uint32_t kSmallTris = 2048;
+constexpr uint32_t kSmallMinDepth = 7;
+constexpr uint32_t kSmallBins = 128;   // bins at kSmallMinDepth: 1024 / 8
+constexpr uint32_t kSmallWaves = 4;
+constexpr uint32_t kMaxStages = 1024;  // local levels (the build stops at depth 512: bins <= 1)
+
+struct SmallRoot {
+  uint32_t node;    // id of the root in the node array
+  uint32_t depth;   // its depth
+  uint32_t region;  // first record of its region in the temporary node array (capacity max_nodes(n))
+};
+
+// flag[i] = 1 for a node of the top tree that k_subtree takes: never visited by the level loop (slot == kNone,
+// still a leaf) with more than 8 triangles; cap[i] = records its subtree may need
+__global__ void k_small_flags(const BNode* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ flag,
+                              uint32_t* __restrict__ cap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const BNode& nd = nodes[i];
+  const uint32_t cnt = nd.end - nd.begin;
+  const bool take = nd.left == 0 && nd.slot == kNone && cnt > kMinTrianglesPerLeaf;
+  flag[i] = take ? 1u : 0u;
+  const uint32_t leaves = cnt / 3 > 1 ? cnt / 3 : 1;
+  cap[i] = take ? 2 * leaves - 1 : 0u;
+}
+__global__ void k_small_list(const BNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ flag,
+                             const uint32_t* __restrict__ rank, const uint32_t* __restrict__ cap_before,
+                             const uint32_t* __restrict__ level_start, uint32_t n_levels, SmallRoot* __restrict__ roots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || !flag[i]) return;
+  uint32_t d = 0;
+  while (d + 1 < n_levels && level_start[d + 1] <= i) d++;
+  roots[rank[i]] = { i, d, cap_before[i] };
+}
+
+// Dynamic LDS: ord[2][kSmallTris], pb[kSmallTris], per wave 27 * kSmallBins words (bins of three axes + suffix boxes)
+__global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
+    const SmallRoot* __restrict__ roots, const BNode* __restrict__ top_nodes, const float4* __restrict__ tbox,
+    uint32_t* __restrict__ order /* in and out: the root's segment */, BNode* __restrict__ tmp,
+    uint32_t* __restrict__ lvl_first /* [region + l]: first local id of local level l */,
+    uint32_t* __restrict__ lvl_base /* [region + l]: rank of that level's first node in stage l */,
+    uint32_t* __restrict__ root_levels /* [root]: local levels */, uint32_t* __restrict__ stage_count,
+    uint32_t* __restrict__ max_depth) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* ord0 = lds;
+  uint32_t* ord1 = lds + kSmallTris;
+  uint32_t* pb = lds + 2 * kSmallTris;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  uint32_t* bins = lds + 3 * kSmallTris + wave * 27 * kSmallBins;
+  __shared__ AxisBest s_best[kSmallWaves][3];
+  __shared__ uint32_t s_next;
+
+  const SmallRoot R = roots[blockIdx.x];
+  const BNode root = top_nodes[R.node];
+  const uint32_t n_root = root.end - root.begin;
+  BNode* nodes = tmp + R.region;
+  for (uint32_t k = threadIdx.x; k < n_root; k += blockDim.x) ord0[k] = order[root.begin + k];
+  if (threadIdx.x == 0) {
+    BNode r0 = root;
+    r0.begin = 0;
+    r0.end = n_root;
+    r0.left = r0.right = 0;
+    r0.size = 1;
+    nodes[0] = r0;
+    lvl_first[R.region] = 0;
+    s_next = 1;
+  }
+  __syncthreads();
+
+  uint32_t* cur = ord0;
+  uint32_t* nxt = ord1;
+  uint32_t lvl_begin = 0, lvl_end = 1, n_levels = 1;
+  for (uint32_t l = 0;; l++) {
+    const uint32_t depth = R.depth + l;
+    const uint32_t num_bins = static_cast<uint32_t>(kMaxBins / static_cast<float>(depth + 1)); // bvh.cpp:145
+    const bool may_split = num_bins > 1;
+    for (uint32_t j = lvl_begin + wave; j < lvl_end; j += kSmallWaves) {
+      const BNode nd = nodes[j];
+      const uint32_t n = nd.end - nd.begin;
+      Choice c;
+      c.axis = -1;
+      c.index = c.left_n = c.child = 0;
+      if (may_split && n > kMinTrianglesPerLeaf) {
+        // k_slot_setup
+        float start[3], inv[3];
+        uint32_t axis_mask = 0;
+        const float fbins = static_cast<float>(num_bins);
+        for (int a = 0; a < 3; a++) {
+          const float step = (nd.top[a] - nd.bot[a]) / fbins;
+          start[a] = nd.bot[a];
+          inv[a] = 1.0f / step;
+          if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) axis_mask |= 1u << a;
+        }
+        const uint32_t num_splits = num_bins - 1;
+        if (axis_mask) {
+          for (uint32_t b = lane; b < 21 * num_bins; b += 64) bins[b] = 0;
+          wave_lds_sync<false>();
+          for (uint32_t k0 = nd.begin + lane; k0 < nd.end; k0 += 256) {
+            uint32_t t[4];
+            float4 top[4], bot[4];
+            for (int q = 0; q < 4; q++) {
+              const uint32_t k = k0 + 64 * q;
+              t[q] = k < nd.end ? cur[k] : kNone;
+            }
+            for (int q = 0; q < 4; q++)
+              if (t[q] != kNone) {
+                top[q] = tbox[2ull * t[q]];
+                bot[q] = tbox[2ull * t[q] + 1];
+              }
+            for (int q = 0; q < 4; q++)
+              if (t[q] != kNone) {
+                uint32_t packed = 0;
+                for (int a = 0; a < 3; a++)
+                  if (axis_mask >> a & 1u) {
+                    uint32_t* ab = bins + a * 7 * num_bins;
+                    const float tp = a == 0 ? top[q].x : (a == 1 ? top[q].y : top[q].z);
+                    const float bt = a == 0 ? bot[q].x : (a == 1 ? bot[q].y : bot[q].z);
+                    const uint32_t b = bin_index((tp + bt) * 0.5f, start[a], inv[a], num_splits);
+                    atomicAdd(&ab[b], 1u);
+                    atomicMax(&ab[num_bins + b], enc(top[q].x));
+                    atomicMax(&ab[2 * num_bins + b], enc(top[q].y));
+                    atomicMax(&ab[3 * num_bins + b], enc(top[q].z));
+                    atomicMax(&ab[4 * num_bins + b], ~enc(bot[q].x));
+                    atomicMax(&ab[5 * num_bins + b], ~enc(bot[q].y));
+                    atomicMax(&ab[6 * num_bins + b], ~enc(bot[q].z));
+                    packed |= b << (10 * a);
+                  }
+                pb[k0 + 64 * q] = packed;
+              }
+          }
+          wave_lds_sync<false>();
+        }
+        float* rb = reinterpret_cast<float*>(bins + 21 * num_bins);
+        for (int a = 0; a < 3; a++) {
+          if (!(axis_mask >> a & 1u)) {
+            if (lane == 0) s_best[wave][a].axis = -1;
+            continue;
+          }
+          const uint32_t* ab = bins + a * 7 * num_bins;
+          auto load = [&](uint32_t b) {
+            CountBox cb;
+            cb.n = ab[b];
+            for (int q = 0; q < 3; q++) {
+              cb.box.top[q] = dec_max(ab[(1 + q) * num_bins + b]);
+              cb.box.bot[q] = dec_min(ab[(4 + q) * num_bins + b]);
+            }
+            return cb;
+          };
+          wave_sah<decltype(load), false>(num_bins, n, a, load, rb, &s_best[wave][a]);
+          wave_lds_sync<false>(); // rb is reused by the next axis
+        }
+        wave_lds_sync<false>();
+        // k_choose
+        float best_cost = cost(nd.top, nd.bot, n);
+        for (int a = 0; a < 3; a++) {
+          const AxisBest& ab = s_best[wave][a];
+          if (ab.axis < 0) continue;
+          if (!(best_cost < ab.cost)) {
+            best_cost = ab.cost;
+            c.axis = a;
+            c.index = ab.index;
+            c.left_n = ab.left_n;
+          }
+        }
+      }
+      if (c.axis >= 0) {
+        // k_make_children
+        uint32_t child = 0;
+        if (lane == 0) child = atomicAdd(&s_next, 2u);
+        child = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(child)));
+        if (lane == 0) {
+          const AxisBest& ab = s_best[wave][c.axis];
+          BNode lc, rc;
+          for (int i = 0; i < 3; i++) {
+            lc.top[i] = ab.ltop[i];
+            lc.bot[i] = ab.lbot[i];
+            rc.top[i] = ab.rtop[i];
+            rc.bot[i] = ab.rbot[i];
+          }
+          lc.begin = nd.begin;
+          lc.end = nd.begin + c.left_n;
+          rc.begin = lc.end;
+          rc.end = nd.end;
+          lc.left = lc.right = rc.left = rc.right = 0;
+          lc.slot = rc.slot = kNone;
+          lc.size = rc.size = 1;
+          nodes[child] = lc;
+          nodes[child + 1] = rc;
+          nodes[j].left = child;
+          nodes[j].right = child + 1;
+        }
+        // stable split (k_goes_left + k_scatter): left part in order, then right part in order
+        uint32_t lbase = nd.begin, rbase = nd.begin + c.left_n;
+        for (uint32_t k0 = nd.begin; k0 < nd.end; k0 += 64) {
+          const uint32_t k = k0 + lane;
+          const bool in = k < nd.end;
+          const bool left = in && ((pb[in ? k : nd.begin] >> (10 * c.axis)) & 1023u) <= c.index;
+          const uint64_t ml = __ballot(left), mr = __ballot(in && !left);
+          const uint64_t below = (1ull << lane) - 1ull;
+          if (left) nxt[lbase + static_cast<uint32_t>(__popcll(ml & below))] = cur[k];
+          else if (in) nxt[rbase + static_cast<uint32_t>(__popcll(mr & below))] = cur[k];
+          lbase += static_cast<uint32_t>(__popcll(ml));
+          rbase += static_cast<uint32_t>(__popcll(mr));
+        }
+      } else {
+        for (uint32_t k = nd.begin + lane; k < nd.end; k += 64) nxt[k] = cur[k]; // a leaf: its segment stays
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t made = s_next;
+    uint32_t* t = cur;
+    cur = nxt;
+    nxt = t;
+    if (made == lvl_end) break; // nothing split at this level
+    lvl_begin = lvl_end;
+    lvl_end = made;
+    if (threadIdx.x == 0) lvl_first[R.region + n_levels] = lvl_begin;
+    n_levels++;
+    __syncthreads();
+  }
+  // the root's segment in its final order
+  for (uint32_t k = threadIdx.x; k < n_root; k += blockDim.x) order[root.begin + k] = cur[k];
+  // subtree sizes, bottom-up over the local levels
+  const uint32_t n_local = lvl_end;
+  for (uint32_t l = n_levels; l-- > 0;) {
+    const uint32_t b = l == 0 ? 0u : lvl_first[R.region + l];
+    const uint32_t e = l + 1 < n_levels ? lvl_first[R.region + l + 1] : n_local;
+    for (uint32_t j = b + threadIdx.x; j < e; j += blockDim.x) {
+      BNode& nd = nodes[j];
+      nd.size = nd.left ? 1u + nodes[nd.left].size + nodes[nd.right].size : 1u;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // a place in every stage for this root's nodes of that local level
+  for (uint32_t l = 1 + threadIdx.x; l < n_levels; l += blockDim.x) {
+    const uint32_t b = lvl_first[R.region + l];
+    const uint32_t e = l + 1 < n_levels ? lvl_first[R.region + l + 1] : n_local;
+    lvl_base[R.region + l] = atomicAdd(&stage_count[l], e - b);
+  }
+  if (threadIdx.x == 0) {
+    root_levels[blockIdx.x] = n_levels;
+    lvl_first[R.region + n_levels] = n_local; // sentinel: end of the last level (capacity >= levels + 1: see k_small_flags)
+    atomicMax(max_depth, R.depth + n_levels - 1);
+  }
+}
+
+// Final ids: node j of local level l >= 1 of root r -> stage_first[l] + lvl_base[r][l] + (j - lvl_first[r][l]).
+// Writes the final records (absolute positions, final child ids), the root's children and size, and node_of
+// for the positions of every leaf.
+__global__ void __launch_bounds__(256) k_subtree_place(const SmallRoot* __restrict__ roots, const BNode* __restrict__ tmp,
+                                                       const uint32_t* __restrict__ lvl_first,
+                                                       const uint32_t* __restrict__ lvl_base,
+                                                       const uint32_t* __restrict__ root_levels,
+                                                       const uint32_t* __restrict__ stage_first, BNode* __restrict__ nodes,
+                                                       uint32_t* __restrict__ node_of) {
+  const SmallRoot R = roots[blockIdx.x];
+  const uint32_t n_levels = root_levels[blockIdx.x];
+  const uint32_t* lf = lvl_first + R.region;
+  const uint32_t* lb = lvl_base + R.region;
+  const BNode* local = tmp + R.region;
+  const uint32_t n_local = lf[n_levels];
+  const uint32_t pos0 = nodes[R.node].begin;
+  auto final_id = [&](uint32_t j, uint32_t l) { return l == 0 ? R.node : stage_first[l] + lb[l] + (j - lf[l]); };
+  for (uint32_t l = 0; l < n_levels; l++) {
+    const uint32_t b = lf[l], e = lf[l + 1];
+    for (uint32_t j = b + threadIdx.x; j < e; j += blockDim.x) {
+      BNode nd = local[j];
+      const uint32_t me = final_id(j, l);
+      if (nd.left) {
+        nd.left = final_id(nd.left, l + 1);
+        nd.right = final_id(nd.right, l + 1);
+      }
+      nd.begin += pos0;
+      nd.end += pos0;
+      nd.slot = kNone;
+      if (l == 0) {
+        BNode& root = nodes[me];
+        root.left = nd.left;
+        root.right = nd.right;
+        root.size = nd.size;
+      } else {
+        nodes[me] = nd;
+      }
+      if (!nd.left)
+        for (uint32_t k = nd.begin; k < nd.end; k++) node_of[k] = me;
+    }
+  }
+  (void) n_local;
+}
+
+// k_flatten for the nodes below a small root, one work-group per root, local level by local level (the root's
+// own record and its children's indices come from k_flatten over the top stages)
+__global__ void __launch_bounds__(256) k_subtree_flatten(const SmallRoot* __restrict__ roots,
+                                                         const uint32_t* __restrict__ lvl_first,
+                                                         const uint32_t* __restrict__ lvl_base,
+                                                         const uint32_t* __restrict__ root_levels,
+                                                         const uint32_t* __restrict__ stage_first, BNode* __restrict__ nodes,
+                                                         uint32_t* __restrict__ flat_index, uint32_t* __restrict__ tri_offset,
+                                                         nova_bvh_node* __restrict__ out) {
+  const SmallRoot R = roots[blockIdx.x];
+  const uint32_t n_levels = root_levels[blockIdx.x];
+  const uint32_t* lf = lvl_first + R.region;
+  const uint32_t* lb = lvl_base + R.region;
+  for (uint32_t l = 1; l < n_levels; l++) {
+    const uint32_t first = stage_first[l] + lb[l], count = lf[l + 1] - lf[l];
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+      BNode& nd = nodes[first + i];
+      const uint32_t me = flat_index[first + i], toff = tri_offset[first + i];
+      nova_bvh_node f;
+      f.top_offset_left = { nd.top[0], nd.top[1], nd.top[2], 0.0f };
+      f.bottom_num_right = { nd.bot[0], nd.bot[1], nd.bot[2], 0.0f };
+      if (!nd.left) {
+        f.top_offset_left.w = static_cast<float>(toff);
+        f.bottom_num_right.w = -static_cast<float>(nd.end - nd.begin);
+      } else {
+        uint32_t a = nd.left, b = nd.right;
+        const BNode& ln = nodes[a];
+        const BNode& rn = nodes[b];
+        if (surface_area(rn.top, rn.bot) > surface_area(ln.top, ln.bot)) { // visit the larger child first
+          a = nd.right;
+          b = nd.left;
+          nd.left = a;
+          nd.right = b;
+        }
+        const BNode& fn = nodes[a];
+        flat_index[a] = me + 1;
+        flat_index[b] = me + 1 + fn.size;
+        tri_offset[a] = toff;
+        tri_offset[b] = toff + (fn.end - fn.begin);
+        f.bottom_num_right.w = static_cast<float>(me + 1 + fn.size);
+      }
+      out[me] = f;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 // ---- flattening (bvh.cpp:211-249) --------------------------------------------------------------------
 __global__ void k_sizes(BNode* __restrict__ nodes, uint32_t ls, uint32_t m) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,8 +1326,11 @@ struct Tree {
   DeviceBuffer nodes;               // BNode[n_nodes]; left = the child visited first
   DeviceBuffer flat_index;          // index of each node in the FlatBVHNode array
   DeviceBuffer tri_offset;          // first triangle (output order) of each node's subtree
-  std::vector<uint32_t> level_start; // nodes of depth d: [level_start[d], level_start[d + 1])
+  // stage s = the id range [level_start[s], level_start[s + 1]): a layering of the tree, every node in a later
+  // stage than its parent (the levels of the top of the tree, then the local levels below the small roots)
+  std::vector<uint32_t> level_start;
   uint32_t n_nodes = 0;
+  uint32_t depth = 0;               // depth of the deepest node (root = 0)
 };
 
 // d_verts: n*9 floats on the device.  d_bvh: room for max_nodes(n) records.  d_tris, d_tri_order: n.
@@ -1020,6 +1390,11 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
                                           node_of[0].as<uint32_t>());
   k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>());
 
+  // NOVA_HIP_BVH_SMALL=0: every level by the level loop (the round-1 builder; A/B and fallback)
+  static const uint32_t small_tris = [] {
+    const char* e = std::getenv("NOVA_HIP_BVH_SMALL");
+    return (e && e[0] == '0') ? 0u : kSmallTris;
+  }();
   std::vector<uint32_t> level_start { 0u };
   uint32_t ls = 0, le = 1; // nodes of the current level
   int cur = 0;
@@ -1031,7 +1406,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     if (num_bins <= 1) break;
     BVHB_TRY(flags.reserve(static_cast<size_t>(m) * 4));
     BVHB_TRY(ranks.reserve(static_cast<size_t>(m) * 4));
-    k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>());
+    k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u,
+                                             flags.as<uint32_t>());
     // the number of nodes to split stays on the device (d_n_slots); the host sizes everything by m
     int rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>(), d_n_slots);
     if (rc) return rc;
@@ -1109,10 +1485,70 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     ls = le;
     le += 2 * n_split;
   }
-  // level_start[d] .. level_start[d + 1] are the nodes of depth d; the last entry is the node count
-  const uint32_t n_nodes = le;
-  const uint32_t n_levels = static_cast<uint32_t>(level_start.size()) - 1;
-  for (uint32_t d = n_levels; d-- > 0;) {
+  // level_start[d] .. level_start[d + 1] are the nodes of depth d of the top of the tree
+  const uint32_t n_top = le;
+  const uint32_t n_top_levels = static_cast<uint32_t>(level_start.size()) - 1;
+  uint32_t n_nodes = n_top, tree_depth = n_top_levels - 1, n_roots = 0;
+  DeviceBuffer roots, tmp_nodes, lvl_first, lvl_base, root_levels, stage_words, d_level_start;
+  if (small_tris) {
+    // the small roots: nodes of the top tree that the level loop left alone
+    BVHB_TRY(flags.reserve(static_cast<size_t>(n_top) * 4));
+    BVHB_TRY(ranks.reserve(static_cast<size_t>(n_top) * 4));
+    BVHB_TRY(gl.reserve(static_cast<size_t>(n_top) * 4));
+    BVHB_TRY(gls.reserve(static_cast<size_t>(n_top) * 4));
+    k_small_flags<<<grid(n_top), kB, 0, stream>>>(nodes.as<BNode>(), n_top, flags.as<uint32_t>(), gl.as<uint32_t>());
+    int rc = scan.run(flags.as<uint32_t>(), n_top, ranks.as<uint32_t>(), d_n_slots);
+    if (rc) return rc;
+    rc = scan.run(gl.as<uint32_t>(), n_top, gls.as<uint32_t>(), d_n_items);
+    if (rc) return rc;
+    BVHB_TRY(hipMemcpyAsync(h_total, d_n_slots, 8, hipMemcpyDeviceToHost, stream)); // d_n_slots, d_n_items are adjacent
+    BVHB_TRY(hipStreamSynchronize(stream));
+    n_roots = h_total[0];
+    const uint32_t total_cap = h_total[1];
+    if (n_roots) {
+      BVHB_TRY(roots.reserve(static_cast<size_t>(n_roots) * sizeof(SmallRoot)));
+      BVHB_TRY(tmp_nodes.reserve(static_cast<size_t>(total_cap) * sizeof(BNode)));
+      BVHB_TRY(lvl_first.reserve(static_cast<size_t>(total_cap) * 4));
+      BVHB_TRY(lvl_base.reserve(static_cast<size_t>(total_cap) * 4));
+      BVHB_TRY(root_levels.reserve(static_cast<size_t>(n_roots) * 4));
+      BVHB_TRY(stage_words.reserve((2 * kMaxStages + 1) * 4)); // counts, first ids, deepest node
+      BVHB_TRY(d_level_start.reserve(level_start.size() * 4));
+      BVHB_TRY(hipMemcpyAsync(d_level_start.p, level_start.data(), level_start.size() * 4, hipMemcpyHostToDevice, stream));
+      BVHB_TRY(hipMemsetAsync(stage_words.p, 0, (2 * kMaxStages + 1) * 4, stream));
+      uint32_t* d_stage_count = stage_words.as<uint32_t>();
+      uint32_t* d_stage_first = d_stage_count + kMaxStages;
+      uint32_t* d_max_depth = d_stage_count + 2 * kMaxStages;
+      k_small_list<<<grid(n_top), kB, 0, stream>>>(nodes.as<BNode>(), n_top, flags.as<uint32_t>(), ranks.as<uint32_t>(),
+                                                  gls.as<uint32_t>(), d_level_start.as<uint32_t>(), n_top_levels,
+                                                  roots.as<SmallRoot>());
+      constexpr size_t kSubtreeLds = (3 * kSmallTris + kSmallWaves * 27 * kSmallBins) * 4;
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_subtree),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSubtreeLds));
+      BVHB_TRY(attr);
+      k_subtree<<<n_roots, kSmallWaves * 64, kSubtreeLds, stream>>>(
+        roots.as<SmallRoot>(), nodes.as<BNode>(), tbox.as<float4>(), order[cur].as<uint32_t>(), tmp_nodes.as<BNode>(),
+        lvl_first.as<uint32_t>(), lvl_base.as<uint32_t>(), root_levels.as<uint32_t>(), d_stage_count, d_max_depth);
+      BVHB_TRY(hipGetLastError());
+      std::vector<uint32_t> stage(2 * kMaxStages + 1);
+      BVHB_TRY(hipMemcpyAsync(stage.data(), stage_words.p, stage.size() * 4, hipMemcpyDeviceToHost, stream));
+      BVHB_TRY(hipStreamSynchronize(stream));
+      // stage l >= 1 = the nodes of local level l of every root, after the top of the tree
+      std::vector<uint32_t> first(kMaxStages, 0u);
+      for (uint32_t l = 1; l < kMaxStages && stage[l]; l++) {
+        first[l] = n_nodes;
+        n_nodes += stage[l];
+        level_start.push_back(n_nodes);
+      }
+      if (n_nodes > cap) return NOVA_HIP_E_BAD_SCENE; // cannot happen
+      tree_depth = stage[2 * kMaxStages] > tree_depth ? stage[2 * kMaxStages] : tree_depth;
+      BVHB_TRY(hipMemcpyAsync(d_stage_first, first.data(), kMaxStages * 4, hipMemcpyHostToDevice, stream));
+      k_subtree_place<<<n_roots, 256, 0, stream>>>(roots.as<SmallRoot>(), tmp_nodes.as<BNode>(), lvl_first.as<uint32_t>(),
+                                                  lvl_base.as<uint32_t>(), root_levels.as<uint32_t>(), d_stage_first,
+                                                  nodes.as<BNode>(), node_of[cur].as<uint32_t>());
+    }
+  }
+  // subtree sizes of the top of the tree (those below the small roots are set), then flattening top-down
+  for (uint32_t d = n_top_levels; d-- > 0;) {
     const uint32_t s = level_start[d], m = level_start[d + 1] - s;
     if (m) k_sizes<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), s, m);
   }
@@ -1120,12 +1556,16 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(tri_offset.reserve(static_cast<size_t>(n_nodes) * 4));
   BVHB_TRY(hipMemsetAsync(flat_index.p, 0, 4, stream));
   BVHB_TRY(hipMemsetAsync(tri_offset.p, 0, 4, stream));
-  for (uint32_t d = 0; d < n_levels; d++) {
+  for (uint32_t d = 0; d < n_top_levels; d++) {
     const uint32_t s = level_start[d], m = level_start[d + 1] - s;
     if (m)
       k_flatten<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), s, m, flat_index.as<uint32_t>(),
                                            tri_offset.as<uint32_t>(), d_bvh);
   }
+  if (n_roots)
+    k_subtree_flatten<<<n_roots, 256, 0, stream>>>(roots.as<SmallRoot>(), lvl_first.as<uint32_t>(), lvl_base.as<uint32_t>(),
+                                                  root_levels.as<uint32_t>(), stage_words.as<uint32_t>() + kMaxStages,
+                                                  nodes.as<BNode>(), flat_index.as<uint32_t>(), tri_offset.as<uint32_t>(), d_bvh);
   k_emit_triangles<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n,
                                               nodes.as<BNode>(), tri_offset.as<uint32_t>(), d_verts, d_tri_order, d_tris);
   BVHB_TRY(hipGetLastError());
@@ -1133,7 +1573,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(hipStreamSynchronize(stream));
   if (result) {
     result->n_nodes = n_nodes;
-    result->levels = n_levels;
+    result->levels = tree_depth + 1;
     result->peak_bin_bytes = peak_bins;
     BVHB_TRY(hipEventElapsedTime(&result->device_ms, ev0, ev1));
   }
@@ -1143,6 +1583,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     keep->tri_offset = std::move(tri_offset);
     keep->level_start = level_start;
     keep->n_nodes = n_nodes;
+    keep->depth = tree_depth;
   }
   return 0;
 }

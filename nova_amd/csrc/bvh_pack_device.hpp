@@ -272,8 +272,9 @@ struct TreeView {
   const BNode* nodes;       // left = the child visited first; size = nodes of the subtree; leaf: end - begin triangles
   const uint32_t* tri_offset; // first triangle of each leaf
   const uint32_t* ids;      // level lists, or null when level d is the id range [level_start[d], level_start[d + 1])
-  const std::vector<uint32_t>* level_start;
+  const std::vector<uint32_t>* level_start; // stages: every node in a later stage than its parent
   uint32_t n_nodes;
+  uint32_t depth;           // depth of the deepest node (root = 0)
 };
 
 inline int pack(hipStream_t stream, const TreeView& tree, const float4* d_tris, Packed* out) {
@@ -284,7 +285,7 @@ inline int pack(hipStream_t stream, const TreeView& tree, const float4* d_tris, 
   const uint32_t n_inner = (n_nodes - 1) / 2, n_leaves = (n_nodes + 1) / 2;
   const std::vector<uint32_t>& level_start = *tree.level_start;
   const uint32_t n_levels = static_cast<uint32_t>(level_start.size()) - 1;
-  if (n_levels - 1 > 64) return 1; // the host path reports it (the reference's own STACK_SIZE)
+  if (tree.depth > 64) return 1; // the host path reports it (the reference's own STACK_SIZE)
   const BNode* nodes = tree.nodes;
   const uint32_t* tri_offset = tree.tri_offset;
   const uint32_t* ids = tree.ids;
@@ -376,7 +377,7 @@ inline int pack(hipStream_t stream, const TreeView& tree, const float4* d_tris, 
 
   out->n_packed = n_inner;
   out->n_wide = n_wide;
-  out->stack_need = n_levels - 1; // deepest leaf: Packer::max_depth
+  out->stack_need = tree.depth; // deepest leaf: Packer::max_depth
   out->stack_need_wide = stack_need_wide;
   out->radius = radius;
   out->nodes = nodes64.as<Node64>();
@@ -389,7 +390,7 @@ inline int pack(hipStream_t stream, const TreeView& tree, const float4* d_tris, 
 }
 
 inline int pack(hipStream_t stream, const bvhb::Tree& tree, const float4* d_tris, Packed* out) {
-  const TreeView v { tree.nodes.as<BNode>(), tree.tri_offset.as<uint32_t>(), nullptr, &tree.level_start, tree.n_nodes };
+  const TreeView v { tree.nodes.as<BNode>(), tree.tri_offset.as<uint32_t>(), nullptr, &tree.level_start, tree.n_nodes, tree.depth };
   return pack(stream, v, d_tris, out);
 }
 
@@ -570,7 +571,8 @@ inline int pack_flat(hipStream_t stream, const nova_bvh_node* d_bvh, uint32_t n_
   PACKDEV_TRY(hipMemcpyAsync(d_level_first, level_first, sizeof(level_first), hipMemcpyHostToDevice, stream));
   k_flat_levels<<<grid(n_nodes), kB, 0, stream>>>(depth.as<uint32_t>(), n_nodes, d_level_first, d_cursor,
                                                  ids.as<uint32_t>());
-  const TreeView v { nodes.as<BNode>(), tri_offset.as<uint32_t>(), ids.as<uint32_t>(), &level_start, n_nodes };
+  const TreeView v { nodes.as<BNode>(), tri_offset.as<uint32_t>(), ids.as<uint32_t>(), &level_start, n_nodes,
+                     static_cast<uint32_t>(level_start.size()) - 2 };
   return pack(stream, v, d_tris, out);
 }
 

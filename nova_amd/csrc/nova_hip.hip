@@ -1932,7 +1932,7 @@ int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nov
   drop_scenes_using(bvh_out);
   drop_scenes_using(triangles_out);
   // the traversal layout from the builder's own tree, so that the first launch does not repack on the host
-  if (!host_pack_only() && tree.level_start.size() - 1 <= 65) {
+  if (!host_pack_only() && tree.depth <= 64) {
     packdev::Packed pd;
     const auto t0 = std::chrono::steady_clock::now();
     rc = packdev::pack(g.stream, tree, reinterpret_cast<const float4*>(triangles_out), &pd);

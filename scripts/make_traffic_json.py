@@ -33,7 +33,8 @@ json.dump({
     "fetch_bytes_per_launch_raw": round(fetch), "write_bytes_per_launch": round(write),
     "hbm_bytes_per_launch": round(2 * fetch + write),
     "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 correction for 16-B-per-lane reads; an upper bound "
-            "for this kernel's gathers) + WRITE_SIZE, averaged over the kernel's dispatches of "
-            "scripts/prof_run.py (dragon stand-in 1080p, max_depth 5, 2 frames)",
+            "for this kernel's gathers) + WRITE_SIZE, averaged over the kernel's dispatches of the profiled "
+            "program (scripts/prof_run.py: dragon stand-in 1080p, max_depth 5, 2 frames; scripts/bench_c4.py --prof: "
+            "two 16.7 M-ray batches on the 10 M-triangle soup).  rocprofv3 sums a counter over the 8 XCDs.",
 }, open(out, "w"), indent=1)
 print(open(out).read())
