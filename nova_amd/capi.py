@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnova_hip.so")
+LIB_PATH = os.environ.get("NOVA_HIP_LIB") or os.path.join(_HERE, "libnova_hip.so")  # NOVA_HIP_LIB: A/B builds of the same library
 
 # option ids (include/nova_hip.h)
 OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT_TRAVERSE_KERNEL, OPT_TUNE = \

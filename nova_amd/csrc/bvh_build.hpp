@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <utility>
@@ -1342,6 +1343,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
 
   DeviceBuffer tbox, order[2], node_of[2], nodes, misc, flags, ranks, slots, items, item_base, multi_list, bins,
     partials, part_owner, pbins, axis_best, choice, gl, gls, flat_index, tri_offset;
+  DeviceBuffer roots, tmp_nodes, lvl_first, lvl_base, root_levels, stage_words, d_level_start;
   BVHB_TRY(tbox.reserve(static_cast<size_t>(n) * 32));
   for (int i = 0; i < 2; i++) {
     BVHB_TRY(order[i].reserve(static_cast<size_t>(n) * 4));
@@ -1373,6 +1375,57 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     return 0;
   };
 
+  // NOVA_HIP_BVH_SMALL=0: every level by the level loop (the round-1 builder; A/B and fallback)
+  static const uint32_t small_tris = [] {
+    const char* e = std::getenv("NOVA_HIP_BVH_SMALL");
+    return (e && e[0] == '0') ? 0u : kSmallTris;
+  }();
+  // Everything the level loop needs, reserved before the clock starts: a buffer that grows inside the loop
+  // costs a hipFree (a device-wide wait) and a hipMalloc per level.  With the small-subtree path a level of the
+  // top tree holds at most ~2 n / kSmallTris nodes above kSmallMinDepth; the in-loop reserves stay as a backstop.
+  {
+    const uint64_t m_bound = small_tris ? std::min<uint64_t>(cap, 2ull * (n / small_tris) + (2ull << kSmallMinDepth)) : cap;
+    BVHB_TRY(flags.reserve(m_bound * 4));
+    BVHB_TRY(ranks.reserve(m_bound * 4));
+    BVHB_TRY(slots.reserve(m_bound * sizeof(Slot)));
+    BVHB_TRY(items.reserve(m_bound * 4));
+    BVHB_TRY(item_base.reserve(m_bound * 4));
+    BVHB_TRY(axis_best.reserve(m_bound * 3 * sizeof(AxisBest)));
+    BVHB_TRY(choice.reserve(m_bound * sizeof(Choice)));
+    size_t max_part = 0, max_bins = 0, max_owner = 0, max_multi_list = 0;
+    for (uint32_t d = 0; d < 64; d++) {
+      const uint32_t nb = static_cast<uint32_t>(kMaxBins / static_cast<float>(d + 1));
+      if (nb <= 1) break;
+      uint32_t chunk = 16 * nb;
+      const uint32_t spread = (n / 2048 + 63) & ~63u;
+      if (chunk > spread) chunk = spread;
+      if (chunk < 1024) chunk = 1024;
+      const uint64_t level_nodes = std::min<uint64_t>(m_bound, 1ull << std::min<uint32_t>(d, 40u));
+      const uint64_t mm = std::min<uint64_t>(n / chunk, level_nodes);
+      const uint64_t parts = mm ? 2ull * (n / chunk) + 1 : 0;
+      max_part = std::max<size_t>(max_part, parts * 21 * nb * 4 + 16);
+      max_owner = std::max<size_t>(max_owner, parts * 4 + 16);
+      max_bins = std::max<size_t>(max_bins, mm * 3 * nb * sizeof(Bin) + 16);
+      max_multi_list = std::max<size_t>(max_multi_list, (mm + 1) * 4);
+    }
+    BVHB_TRY(partials.reserve(max_part));
+    BVHB_TRY(part_owner.reserve(max_owner));
+    BVHB_TRY(bins.reserve(max_bins));
+    BVHB_TRY(multi_list.reserve(max_multi_list));
+    BVHB_TRY(scan.sums.reserve((static_cast<size_t>(n) / kScanTile + 2) * 4));
+    if (small_tris) { // a small root has more than 8 triangles; its region holds max_nodes(its triangles) records
+      const size_t max_roots = n / (kMinTrianglesPerLeaf + 1) + 1;
+      BVHB_TRY(roots.reserve(max_roots * sizeof(SmallRoot)));
+      BVHB_TRY(root_levels.reserve(max_roots * 4));
+      BVHB_TRY(tmp_nodes.reserve(cap * sizeof(BNode)));
+      BVHB_TRY(lvl_first.reserve(cap * 4));
+      BVHB_TRY(lvl_base.reserve(cap * 4));
+      BVHB_TRY(stage_words.reserve((2 * kMaxStages + 1) * 4));
+      BVHB_TRY(d_level_start.reserve(1024 * 4));
+      BVHB_TRY(flat_index.reserve(cap * 4));
+      BVHB_TRY(tri_offset.reserve(cap * 4));
+    }
+  }
   hipEvent_t ev0, ev1;
   BVHB_TRY(hipEventCreate(&ev0));
   BVHB_TRY(hipEventCreate(&ev1));
@@ -1390,11 +1443,6 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
                                           node_of[0].as<uint32_t>());
   k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>());
 
-  // NOVA_HIP_BVH_SMALL=0: every level by the level loop (the round-1 builder; A/B and fallback)
-  static const uint32_t small_tris = [] {
-    const char* e = std::getenv("NOVA_HIP_BVH_SMALL");
-    return (e && e[0] == '0') ? 0u : kSmallTris;
-  }();
   std::vector<uint32_t> level_start { 0u };
   uint32_t ls = 0, le = 1; // nodes of the current level
   int cur = 0;
@@ -1489,7 +1537,6 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   const uint32_t n_top = le;
   const uint32_t n_top_levels = static_cast<uint32_t>(level_start.size()) - 1;
   uint32_t n_nodes = n_top, tree_depth = n_top_levels - 1, n_roots = 0;
-  DeviceBuffer roots, tmp_nodes, lvl_first, lvl_base, root_levels, stage_words, d_level_start;
   if (small_tris) {
     // the small roots: nodes of the top tree that the level loop left alone
     BVHB_TRY(flags.reserve(static_cast<size_t>(n_top) * 4));
