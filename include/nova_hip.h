@@ -323,6 +323,9 @@ enum {
                                    rest of every image as it is; kernel_post_process and nova_hip_render_samples
                                    refuse anti_aliasing (FXAA reads across tiles): see nova_hip_tiles_pack */
   NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* internal A/B switch between traversal kernel variants */
+  NOVA_HIP_OPT_SORT_RAYS = 8,   /* nova_hip_trace_rays: bin the batch by origin cell and direction octant before tracing
+                                   (same hits; fewer HBM lines per ray). 0 = for batches of >= 2^20 rays over scenes
+                                   larger than 256 MB (default), 1 = never, 2 = always */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

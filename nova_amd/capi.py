@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NOVA_HIP_LIB") or os.path.join(_HERE, "libnova_hip.so")  # NOVA_HIP_LIB: A/B builds of the same library
 
 # option ids (include/nova_hip.h)
-OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT_TRAVERSE_KERNEL, OPT_TUNE = \
-    1, 2, 3, 4, 5, 6, 7
+OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT_TRAVERSE_KERNEL, OPT_TUNE, OPT_SORT_RAYS = \
+    1, 2, 3, 4, 5, 6, 7, 8
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 

@@ -145,6 +145,13 @@ struct Ctx {
   uint32_t* d_spill = nullptr;           // traversal stack entries beyond the LDS part
   size_t spill_words = 0;
   TilePlan plan;
+  // ray binning of nova_hip_trace_rays (traverse.hpp: k_ray_keys): keys, permutation, histogram / cursors
+  uint32_t* d_ray_keys = nullptr;
+  uint32_t* d_ray_perm = nullptr;
+  uint32_t* d_ray_hist = nullptr;
+  size_t ray_sort_capacity = 0;
+  bvhb::Scanner ray_scan;
+  int64_t opt_sort_rays = 0;
   // denoise hand-off: four float3 planes (colour, albedo, normal, output) on the device and pinned on the host
   float* d_denoise = nullptr;
   float* h_denoise = nullptr;
@@ -931,6 +938,9 @@ int nova_hip_shutdown(void) {
   for (auto& s : g.scenes) free_scene(s);
   g.scenes.clear();
   free_tile_plan();
+  (void) hipFree(g.d_ray_keys);
+  (void) hipFree(g.d_ray_perm);
+  (void) hipFree(g.d_ray_hist);
   (void) hipFree(g.d_denoise);
   (void) hipHostFree(g.h_denoise);
   free_frame_buffers(g.fb);
@@ -1106,6 +1116,9 @@ int nova_hip_set_option(int option, int64_t value) {
       g.opt_tile_ranks = value; return 0;
     case NOVA_HIP_OPT_TRAVERSE_KERNEL: g.opt_kernel = value; return 0;
     case NOVA_HIP_OPT_TUNE: g.opt_tune = value; return 0;
+    case NOVA_HIP_OPT_SORT_RAYS:
+      if (value < 0 || value > 2) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_sort_rays = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1120,6 +1133,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_TILE_RANKS: *value = g.opt_tile_ranks; return 0;
     case NOVA_HIP_OPT_TRAVERSE_KERNEL: *value = g.opt_kernel; return 0;
     case NOVA_HIP_OPT_TUNE: *value = g.opt_tune; return 0;
+    case NOVA_HIP_OPT_SORT_RAYS: *value = g.opt_sort_rays; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1837,6 +1851,46 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   T.kinds = 1;
   T.stride = 0;
   T.queue_head = queue_heads;
+  // large batches over a scene that does not fit the caches: bin the rays first (NOVA_HIP_OPT_SORT_RAYS)
+  const size_t scene_bytes = static_cast<size_t>(scene->n_wide) * sizeof(Node128) + static_cast<size_t>(scene->n_tris) * 48;
+  const bool sort = scene->wide != nullptr && g.opt_traversal == 0 && (g.opt_kernel == 0 || g.opt_kernel == 7 || g.opt_kernel == 14 || g.opt_kernel >= 20) &&
+                    (g.opt_sort_rays == 2 || (g.opt_sort_rays == 0 && num_rays >= (1u << 20) && scene_bytes > (256u << 20)));
+  if (sort) {
+    const uint32_t n = static_cast<uint32_t>(num_rays);
+    const uint32_t n_keys = 1u << kRayKeyBits;
+    if (g.ray_sort_capacity < num_rays) {
+      HIP_TRY(hipStreamSynchronize(g.stream));
+      (void) hipFree(g.d_ray_keys);
+      (void) hipFree(g.d_ray_perm);
+      g.d_ray_keys = g.d_ray_perm = nullptr;
+      g.ray_sort_capacity = 0;
+      HIP_TRY(hipMalloc(&g.d_ray_keys, num_rays * 4));
+      HIP_TRY(hipMalloc(&g.d_ray_perm, num_rays * 4));
+      if (!g.d_ray_hist) HIP_TRY(hipMalloc(&g.d_ray_hist, (2 * n_keys + 16) * 4));
+      g.ray_sort_capacity = num_rays;
+    }
+    uint32_t* hist = g.d_ray_hist;
+    uint32_t* cursor = g.d_ray_hist + n_keys;
+    HIP_TRY(hipMemsetAsync(hist, 0, n_keys * 4, g.stream));
+    float s[3];
+    for (int a = 0; a < 3; a++) {
+      const float ext = scene->root_top[a] - scene->root_bot[a];
+      s[a] = ext > 0.0f ? 32.0f / ext : 0.0f;
+    }
+    hipEvent_t e0 = nullptr;
+    span_begin(&e0);
+    hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, g.stream, T.ray_o, T.ray_d, n, scene->root_bot[0],
+                       scene->root_bot[1], scene->root_bot[2], s[0], s[1], s[2], g.d_ray_keys, hist);
+    g.ray_scan.stream = g.stream;
+    g.ray_scan.d_total = cursor + n_keys;
+    rc = g.ray_scan.run(hist, n_keys, cursor);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ray_scatter, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_ray_keys, n, cursor, g.d_ray_perm);
+    HIP_TRY(hipGetLastError());
+    hipEvent_t e1 = span_end();
+    if (e0 && e1) g.ev_traverse.push_back({ e0, e1 }); // part of the batch's traversal time
+    T.perm = g.d_ray_perm;
+  }
   rc = launch_traverse(*scene, T, false);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));

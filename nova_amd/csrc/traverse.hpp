@@ -91,7 +91,44 @@ struct TraverseArgs {
   uint32_t n_tris;
   uint32_t rays_per_wave;            // k_traverse_p: largest number of rays a wave takes from the queue at a time
   uint32_t flags;                    // bits 0-1 = RayQueue mode, bit 2 = ray kinds interleaved
+  const uint32_t* perm;              // k_traverse_p: queue position w takes ray perm[w] (rays binned by origin cell and
+                                     // direction octant, k_ray_keys), or null
 };
+
+// ---- ray binning for incoherent batches -------------------------------------------------------------
+// A batch of random rays over a scene that does not fit the caches (BASELINE config 4: 0.6 GB of nodes and
+// triangles) is bound by HBM: every ray pulls its own lines.  Rays that start in the same cell of a 32^3 grid
+// over the root box and point into the same octant walk much the same nodes, so the queue is read through a
+// permutation that puts them next to each other (counting sort on an 18-bit key: Morton code of the cell, then
+// the octant).  Which ray a lane traces does not change the ray's answer; hits go to the ray's own slot.
+constexpr uint32_t kRayKeyBits = 18;
+__device__ __forceinline__ uint32_t spread5(uint32_t v) { // 5 bits -> every third bit
+  v = (v | (v << 8)) & 0x100Fu;
+  v = (v | (v << 4)) & 0x10C3u;
+  v = (v | (v << 2)) & 0x1249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_ray_keys(const float4* __restrict__ ray_o, const float4* __restrict__ ray_d, uint32_t n,
+                                                  float bx, float by, float bz, float sx, float sy, float sz,
+                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ hist) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 o = ray_o[i], d = ray_d[i];
+  const float fx = (o.x - bx) * sx, fy = (o.y - by) * sy, fz = (o.z - bz) * sz;
+  const uint32_t cx = fx > 0.0f ? min(static_cast<uint32_t>(fminf(fx, 31.0f)), 31u) : 0u;
+  const uint32_t cy = fy > 0.0f ? min(static_cast<uint32_t>(fminf(fy, 31.0f)), 31u) : 0u;
+  const uint32_t cz = fz > 0.0f ? min(static_cast<uint32_t>(fminf(fz, 31.0f)), 31u) : 0u;
+  const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+  const uint32_t key = ((spread5(cx) | (spread5(cy) << 1) | (spread5(cz) << 2)) << 3) | oct;
+  keys[i] = key;
+  atomicAdd(&hist[key], 1u);
+}
+__global__ __launch_bounds__(256) void k_ray_scatter(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ cursor,
+                                                     uint32_t* __restrict__ perm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  perm[atomicAdd(&cursor[keys[i]], 1u)] = i;
+}
 
 // Per-leaf cull slack (see the header comment).  For a ray with |origin| <= R and a hit inside
 // the scene box, the barycentric u = ox + t*dx is evaluated with absolute error
@@ -680,6 +717,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
             kind = w - j * A.kinds;
           }
           slot = static_cast<size_t>(kind) * A.stride + j;
+          if (A.perm) slot = A.perm[w];
           const float4 o4 = A.ray_o[slot];
           const float4 d4 = A.ray_d[slot];
           h = { o4.w, 0.0f, 0.0f, -1 };
