@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   RayState r = {};
   HitState h = { 0.0f, 0.0f, 0.0f, -1 };
   float slack_scale = 0.0f, far_limit = 0.0f;
+  float o_scale = 1.0f; // max(1, |origin| / scene radius): the slack is per unit of that (k_leaf_slack)
   bool anyhit = false;
   bool pair = false; // this lane's ray walks the box-pair tree (non-finite 1/d or -o/d)
   uint32_t cur = kDone;
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
             const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
             slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
                           max_(1.0f, o_inf * A.inv_radius);
+            o_scale = max_(1.0f, o_inf * A.inv_radius);
             far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
             st.sp = 0;
             cur = 0;
@@ -781,6 +783,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         r.nio.x = __shfl(r.nio.x, src); r.nio.y = __shfl(r.nio.y, src); r.nio.z = __shfl(r.nio.z, src);
         h.t = __shfl(h.t, src); h.u = __shfl(h.u, src); h.v = __shfl(h.v, src); h.id = __shfl(h.id, src);
         slack_scale = __shfl(slack_scale, src);
+        o_scale = __shfl(o_scale, src);
         far_limit = __shfl(far_limit, src);
         anyhit = __shfl(anyhit ? 1 : 0, src) != 0;
         fam = __shfl(fam, src);
@@ -844,14 +847,22 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         const float hxs[4] = { hx.x, hx.y, hx.z, hx.w }, hys[4] = { hy.x, hy.y, hy.z, hy.w }, hzs[4] = { hz.x, hz.y, hz.z, hz.w };
         const float ess[4] = { es.x, es.y, es.z, es.w };
         uint32_t n_hit = 0;
+        // Near side of the cull: "the box widened by the child's slack e lies behind the origin".  The ray leaves
+        // that box at min over the axes of far_a + e |1/d_a| — its slab test — which is far tighter than
+        // far + e max |1/d| for a ray with one small direction component, and boxes just behind the origin
+        // are what a bounce ray meets first: 4 % fewer node visits and 11 % fewer triangle tests on the
+        // benchmark frame.  (The far side keeps the one-product bound: it decides 1.7 % of the visits.)
+        const float ax = __builtin_fabsf(r.inv.x) * o_scale, ay = __builtin_fabsf(r.inv.y) * o_scale, az = __builtin_fabsf(r.inv.z) * o_scale;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const float t1x = fma_(hxs[k], r.inv.x, r.nio.x), t1y = fma_(hys[k], r.inv.y, r.nio.y), t1z = fma_(hzs[k], r.inv.z, r.nio.z);
           const float t2x = fma_(lxs[k], r.inv.x, r.nio.x), t2y = fma_(lys[k], r.inv.y, r.nio.y), t2z = fma_(lzs[k], r.inv.z, r.nio.z);
           const float tn = max_(min_(t1x, t2x), max_(min_(t1y, t2y), min_(t1z, t2z)));
-          const float tf = min_(max_(t1x, t2x), min_(max_(t1y, t2y), max_(t1z, t2z)));
+          const float fx = max_(t1x, t2x), fy = max_(t1y, t2y), fz = max_(t1z, t2z);
+          const float tf = min_(fx, min_(fy, fz));
           const float e = ess[k] * slack_scale;
-          const bool hit = (tn <= tf) && (tf + e >= 0.0f) && (tn - e <= far_limit);
+          const float near = min_(fma_(ess[k], ax, fx), min_(fma_(ess[k], ay, fy), fma_(ess[k], az, fz)));
+          const bool hit = (tn <= tf) && (near >= 0.0f) && (tn - e <= far_limit);
           key[k] = hit ? min_(tn, 3.402823466e38f) : inf;
           n_hit += hit ? 1u : 0u;
         }
