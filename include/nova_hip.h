@@ -326,6 +326,12 @@ enum {
   NOVA_HIP_OPT_SORT_RAYS = 8,   /* nova_hip_trace_rays: bin the batch by origin cell and direction octant before tracing
                                    (same hits; fewer HBM lines per ray). 0 = for batches of >= 2^20 rays over scenes
                                    larger than 256 MB (default), 1 = never, 2 = always */
+  NOVA_HIP_OPT_CLAMP_TO_EDGE = 9, /* what NOVA_ADDRESS_CLAMP means for the frame images that kernel_accumulate and
+                                     kernel_post_process sample.  0 (default): the OpenCL backend's CLK_ADDRESS_CLAMP — texels
+                                     beyond the image read as 0 (kernels/backend/opencl/image.hpp:14-21).  1: the CUDA backend's
+                                     cudaAddressModeClamp — the edge texel repeats (src/backend/cuda/types/flags.hpp:30).
+                                     Only FXAA's taps at the outermost pixel ring can tell the difference.  The address mode is
+                                     all the switch changes: CUDA's 9-bit filter weights are not modelled. */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

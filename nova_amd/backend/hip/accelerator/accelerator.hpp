@@ -33,6 +33,8 @@ public:
   //   NOVA_HIP_FIXED_SEED  replaces the wall-clock `time` argument by seed + launch counter
   //   NOVA_HIP_TILE_RANK / NOVA_HIP_TILE_RANKS   multi-GPU: this process (one per GPU) renders the 64x64
   //                        tiles t with t % RANKS == RANK (nova_hip.h: NOVA_HIP_OPT_TILE_RANK/RANKS)
+  //   NOVA_HIP_CLAMP_TO_EDGE=1  AddressMode::CLAMP as the CUDA backend's clamp-to-edge; default = the OpenCL
+  //                        backend's border colour 0 (nova_hip.h: NOVA_HIP_OPT_CLAMP_TO_EDGE)
   Accelerator() {
     const char* dev = std::getenv("NOVA_HIP_DEVICE");
     HIP_CHECK_AND_THROW(nova_hip_init(dev ? std::atoi(dev) : 0));
@@ -43,6 +45,9 @@ public:
       const char* r = std::getenv("NOVA_HIP_TILE_RANK");
       HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_TILE_RANKS, std::atoll(n)));
       HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_TILE_RANK, r ? std::atoll(r) : 0));
+    }
+    if (const char* c = std::getenv("NOVA_HIP_CLAMP_TO_EDGE")) {
+      HIP_CHECK_AND_THROW(nova_hip_set_option(NOVA_HIP_OPT_CLAMP_TO_EDGE, std::atoll(c) != 0 ? 1 : 0));
     }
     if (const char* s = std::getenv("NOVA_HIP_FIXED_SEED")) {
       fixed_seed = true;

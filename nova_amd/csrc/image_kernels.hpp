@@ -20,20 +20,25 @@ struct AccumulateArgs {
   float4 *color2, *albedo2, *normal2;
   uint32_t width, height;
   const uint8_t* mask; // tile partition: per pixel, bit 0 = own tile, bit 1 = halo pixel kept as well; null = every pixel
+  bool edge;           // ImageView::edge of the images read
 };
 
 // sample_linear<false> at a pixel centre under a tile partition: texels this rank does not keep (mask 0) read
 // as 0 without being loaded.  Every tap with a non-zero weight is kept by construction (TilePlan), so for
 // finite images this is sample_linear<false> bit for bit — and whatever another rank's pixels hold in this
 // rank's memory (never written here; possibly NaN) cannot reach its own pixels through a zero weight.
-NV_DEV V3 sample_kept(const float4* p, const uint8_t* mask, int w, int h, float s, float t) {
+NV_DEV V3 sample_kept(const float4* p, const uint8_t* mask, int w, int h, float s, float t, bool edge) {
   const float u = s * static_cast<float>(w), v = t * static_cast<float>(h);
   const int i0 = static_cast<int>(__builtin_floorf(u - 0.5f)), j0 = static_cast<int>(__builtin_floorf(v - 0.5f));
   const int i1 = i0 + 1, j1 = j0 + 1;
   const float a = (u - 0.5f) - __builtin_floorf(u - 0.5f);
   const float b = (v - 0.5f) - __builtin_floorf(v - 0.5f);
   auto tx = [&](int i, int j) {
-    if (i < 0 || j < 0 || i >= w || j >= h) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < 0 || j < 0 || i >= w || j >= h) {
+      if (!edge) return make_float4(0.f, 0.f, 0.f, 0.f);
+      i = min(max(i, 0), w - 1);
+      j = min(max(j, 0), h - 1);
+    }
     const size_t k = static_cast<size_t>(j) * w + i;
     return mask[k] ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumulateArgs A) {
     const float u = (static_cast<float>(static_cast<int>(x)) + 0.5f) / static_cast<float>(A.width);
     const float v = (static_cast<float>(static_cast<int>(y)) + 0.5f) / static_cast<float>(A.height);
     auto ld = [&](const float4* p) {
-      return A.mask ? sample_kept(p, A.mask, w, h, u, v) : sample_linear<false>(ImageView { p, w, h, 1, nullptr, nullptr }, u, v, 0);
+      return A.mask ? sample_kept(p, A.mask, w, h, u, v, A.edge)
+                    : sample_linear<false>(ImageView { p, w, h, 1, nullptr, nullptr, A.edge }, u, v, 0);
     };
     V3 c = ld(A.color1);
     V3 a { 0.f, 0.f, 0.f }, n { 0.f, 0.f, 0.f };
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void k_post_process(PostArgs A) {
     if (A.anti_aliasing) {
       c = fxaa(A.color2, inv_w, inv_h, u, v);
     } else if (A.mask) {
-      c = sample_kept(A.color2.texels, A.mask, A.color2.w, A.color2.h, u, v);
+      c = sample_kept(A.color2.texels, A.mask, A.color2.w, A.color2.h, u, v, A.color2.edge);
     } else {
       c = sample_linear<false>(A.color2, u, v, 0);
     }

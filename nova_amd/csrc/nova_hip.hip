@@ -160,7 +160,7 @@ struct Ctx {
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
   int64_t opt_max_depth = 0, opt_traversal = 0, opt_count_work = 0, opt_tile_rank = 0,
-          opt_tile_ranks = 1, opt_kernel = 0, opt_tune = 0;
+          opt_tile_ranks = 1, opt_kernel = 0, opt_tune = 0, opt_clamp_to_edge = 0;
   // timing
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -1119,6 +1119,9 @@ int nova_hip_set_option(int option, int64_t value) {
     case NOVA_HIP_OPT_SORT_RAYS:
       if (value < 0 || value > 2) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_sort_rays = value; return 0;
+    case NOVA_HIP_OPT_CLAMP_TO_EDGE:
+      if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_clamp_to_edge = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1134,6 +1137,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_TRAVERSE_KERNEL: *value = g.opt_kernel; return 0;
     case NOVA_HIP_OPT_TUNE: *value = g.opt_tune; return 0;
     case NOVA_HIP_OPT_SORT_RAYS: *value = g.opt_sort_rays; return 0;
+    case NOVA_HIP_OPT_CLAMP_TO_EDGE: *value = g.opt_clamp_to_edge; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1392,6 +1396,9 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
                        materials, sky, denoise_available, albedo_feature1, normal_feature1, true);
 }
 
+// NOVA_HIP_OPT_CLAMP_TO_EDGE for an image created with NOVA_ADDRESS_CLAMP
+static bool clamp_to_edge(const nova_hip_image* im) { return g.opt_clamp_to_edge != 0 && im->address_mode == NOVA_ADDRESS_CLAMP; }
+
 // ---- kernel_accumulate -------------------------------------------------------------------------
 static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
                            const nova_hip_image* temp_color1, const nova_hip_image* albedo_feature1,
@@ -1428,6 +1435,7 @@ static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
   A.width = width;
   A.height = height;
   A.mask = nullptr;
+  A.edge = clamp_to_edge(temp_color1);
   if (g.opt_tile_ranks > 1) { // this rank's pixels only (its tiles + their halo)
     if (g.opt_tile_rank >= g.opt_tile_ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
     rc = ensure_tile_plan(width, height);
@@ -1464,7 +1472,7 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
     return NOVA_HIP_E_INVALID_ARGUMENT;
   PostArgs A;
   A.color2 = { static_cast<const float4*>(temp_color2->data), static_cast<int>(width), static_cast<int>(height), 1,
-               nullptr, nullptr };
+               nullptr, nullptr, clamp_to_edge(temp_color2) };
   A.pixels = static_cast<uchar4*>(pixels->data);
   A.width = width;
   A.height = height;

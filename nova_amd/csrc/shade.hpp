@@ -28,6 +28,7 @@ struct ImageView {
   // lut[x] = float(x) / 255.0f (k_shade fills it in LDS with the same correctly rounded division).
   const uchar4* u8;
   const float* lut;
+  bool edge; // CLAMP repeats the edge texel (NOVA_HIP_OPT_CLAMP_TO_EDGE) instead of reading 0 beyond the image
 };
 
 struct PathPlanes {
@@ -74,7 +75,11 @@ constexpr uint32_t kShadeBlock = 1024; // one compaction atomic per 1024 paths
 // coordinates; repeat = CLK_ADDRESS_REPEAT, else CLK_ADDRESS_CLAMP (border colour 0), which is
 // what the reference's float-coordinate samplers are (kernels/backend/opencl/image.hpp:14-21).
 NV_DEV float4 texel(const ImageView& im, int i, int j, int layer) {
-  if (i < 0 || j < 0 || i >= im.w || j >= im.h) return make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < 0 || j < 0 || i >= im.w || j >= im.h) {
+    if (!im.edge) return make_float4(0.f, 0.f, 0.f, 0.f);
+    i = min(max(i, 0), im.w - 1);
+    j = min(max(j, 0), im.h - 1);
+  }
   const size_t k = (static_cast<size_t>(layer) * im.h + j) * im.w + i;
   if (im.u8) {
     const uchar4 t = im.u8[k];

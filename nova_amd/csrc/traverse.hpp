@@ -851,7 +851,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         // that box at min over the axes of far_a + e |1/d_a| — its slab test — which is far tighter than
         // far + e max |1/d| for a ray with one small direction component, and boxes just behind the origin
         // are what a bounce ray meets first: 4 % fewer node visits and 11 % fewer triangle tests on the
-        // benchmark frame.  (The far side keeps the one-product bound: it decides 1.7 % of the visits.)
+        // benchmark frame.  (The far side keeps the one-product bound: it decides 1.7 % of the visits, and the same
+        // treatment there measured 0.6 %.)
         const float ax = __builtin_fabsf(r.inv.x) * o_scale, ay = __builtin_fabsf(r.inv.y) * o_scale, az = __builtin_fabsf(r.inv.z) * o_scale;
 #pragma unroll
         for (int k = 0; k < 4; k++) {

@@ -30,6 +30,7 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_brdf.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_float,
                                                              ctypes.c_void_p, ctypes.c_void_p]
         _lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        _lib.oracle_set_clamp_to_edge.argtypes = [ctypes.c_int]
     return _lib
 
 
@@ -39,6 +40,11 @@ def _p(a):
 
 def set_threads(n: int):
     lib().oracle_set_threads(int(n))
+
+
+def set_clamp_to_edge(on: bool):
+    """CLAMP beyond the image: False = border colour 0 (OpenCL backend, default), True = edge texel (CUDA backend)."""
+    lib().oracle_set_clamp_to_edge(1 if on else 0)
 
 
 def kernel_raytrace(scene, params, time, width, height, denoise_available=0, meta=None, sky=None,

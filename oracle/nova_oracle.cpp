@@ -324,11 +324,20 @@ bool find_intersection_ordered(const nova_triangle_data* tris, const nova_bvh_no
 }
 
 // ---- images ------------------------------------------------------------------------------------
+// What CLAMP means beyond the image: 0 = the OpenCL backend's border colour 0 (CLK_ADDRESS_CLAMP,
+// kernels/backend/opencl/image.hpp:14-21), 1 = the CUDA backend's clamp to the edge texel
+// (src/backend/cuda/types/flags.hpp:30).  oracle_set_clamp_to_edge.
+int g_clamp_to_edge = 0;
+
 struct Image {
   const float* texels; // rgba
   int w, h, layers;
   f4 at(int i, int j, int layer) const {
-    if (i < 0 || j < 0 || i >= w || j >= h) return { 0, 0, 0, 0 }; // CLAMP = border colour 0
+    if (i < 0 || j < 0 || i >= w || j >= h) {
+      if (!g_clamp_to_edge) return { 0, 0, 0, 0 };
+      i = std::min(std::max(i, 0), w - 1);
+      j = std::min(std::max(j, 0), h - 1);
+    }
     const float* p = texels + 4 * ((static_cast<size_t>(layer) * h + j) * w + i);
     return { p[0], p[1], p[2], p[3] };
   }
@@ -745,6 +754,7 @@ int g_threads = 0;
 extern "C" {
 
 void oracle_set_threads(int n) { g_threads = n; }
+void oracle_set_clamp_to_edge(int on) { g_clamp_to_edge = on ? 1 : 0; }
 
 uint32_t oracle_hash(uint32_t s) { return wang_hash(s); }
 float oracle_rand(uint32_t* st) { return rnd(*st); }

@@ -434,3 +434,33 @@ def test_random_configurations_against_the_oracle_bitwise():
                          cwd=root, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "SOAK OK" in res.stdout
+
+
+def test_clamp_to_edge_option_against_the_oracle():
+    """NOVA_HIP_OPT_CLAMP_TO_EDGE: CLAMP as the CUDA backend's clamp-to-edge instead of the OpenCL
+    backend's border colour 0.  Only FXAA's taps at the outermost pixel ring differ; GPU == oracle in both modes,
+    the ring included, and the two modes agree far from the border."""
+    from oracle import bind as O
+    rng = np.random.default_rng(21)
+    w, h = 112, 96
+    img = rng.uniform(0.0, 2.0, (h, w, 4)).astype(np.float32)
+    img[:, : w // 2] *= 0.1  # a strong vertical edge that runs into the top and bottom borders
+    cam = S.Camera(width=w, height=h, **S.CORNELL_CAMERA)
+    params = S.make_scene_params(cam, anti_aliasing=True, exposure=1.2)
+    src = capi.Image(w, h, data=img)
+    dst = capi.Image(w, h, texel_bytes=4)
+    out = {}
+    try:
+        for mode in (0, 1):
+            capi.set_option(capi.OPT_CLAMP_TO_EDGE, mode)
+            O.set_clamp_to_edge(bool(mode))
+            capi.launch_post_process(params, src, dst, w, h)
+            out[mode] = dst.read().copy()
+            assert (out[mode] == O.kernel_post_process(params, img)).all()
+    finally:
+        capi.set_option(capi.OPT_CLAMP_TO_EDGE, 0)
+        O.set_clamp_to_edge(False)
+    # FXAA searches up to ~26 pixels along an edge (kernels/anti_aliasing.hpp:99-116): farther in than that the
+    # border cannot be seen
+    assert (out[0][32:-32, 32:-32] == out[1][32:-32, 32:-32]).all()
+    assert (out[0] != out[1]).any()  # nearer to it, it can

@@ -235,3 +235,12 @@ def test_running_mean_and_flat_image_post_process():
     assert (plain[inner] == fx[inner]).all()
     want = (1.0 - np.exp(-np.float64([0.3, 0.6, 1.7]) * 1.5)) ** (1 / 2.2) * 255.0
     assert (np.abs(plain[5, 5, :3].astype(np.float64) - np.floor(want)) <= 1).all()
+    # CLAMP as the CUDA backend's clamp-to-edge (oracle_set_clamp_to_edge / NOVA_HIP_OPT_CLAMP_TO_EDGE): no black
+    # ring around the frame, so FXAA leaves the WHOLE flat image alone
+    O.set_clamp_to_edge(True)
+    try:
+        fx_edge = O.kernel_post_process(S.make_scene_params(cam, anti_aliasing=True, exposure=1.5), flat)
+    finally:
+        O.set_clamp_to_edge(False)
+    assert (fx_edge == plain).all()
+    assert (fx != plain).any()  # border colour 0 (the default, OpenCL backend) does touch the ring
