@@ -325,35 +325,51 @@ __device__ __forceinline__ uint32_t bin_index(float c, float start, float inv, u
 }
 
 // ---- split evaluation by one wave (bvh.cpp:54-105) ---------------------------------------------------
+// A count and a box as the bins hold them: max xyz as enc(), min xyz as ~enc() (so that both grow by an unsigned
+// max), all-zero = empty.  The scans below stay in that form — one v_max_u32 with a DPP operand per value and
+// step instead of move + compare + select on floats — and boxes are decoded only where a cost is computed.
+// (enc() orders -0 below +0, std::max as AABB::grow uses it keeps whichever came first: a box coordinate that is
+// a zero of both signs may come out with the other sign than on the host.  No comparison tells the two apart.)
 struct CountBox {
   uint32_t n;
-  Box3 box;
+  uint32_t mx[3]; // enc(max)
+  uint32_t mn[3]; // ~enc(min)
 };
 __device__ __forceinline__ CountBox empty_count_box() {
   CountBox c;
   c.n = 0;
-  for (int i = 0; i < 3; i++) {
-    c.box.top[i] = -kFltMax;
-    c.box.bot[i] = kFltMax;
-  }
+  for (int i = 0; i < 3; i++) c.mx[i] = c.mn[i] = 0u;
   return c;
 }
 __device__ __forceinline__ void combine(CountBox& a, const CountBox& b) {
   a.n += b.n;
-  grow(a.box, b.box);
+  for (int i = 0; i < 3; i++) {
+    a.mx[i] = a.mx[i] < b.mx[i] ? b.mx[i] : a.mx[i];
+    a.mn[i] = a.mn[i] < b.mn[i] ? b.mn[i] : a.mn[i];
+  }
+}
+__device__ __forceinline__ Box3 decode(const CountBox& c) {
+  Box3 r;
+  for (int i = 0; i < 3; i++) {
+    r.top[i] = dec_max(c.mx[i]);
+    r.bot[i] = dec_min(c.mn[i]);
+  }
+  return r;
 }
 // Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves (no LDS traffic):
 // row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3
-// (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).  A lane without a source gets the identity.
+// (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31).  A lane without a source gets the identity (0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void scan_step(CountBox& v) {
   CountBox o;
-  o.n = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v.n), CTRL, ROW_MASK, 0xf, false));
+  o.n = dpp0<CTRL, ROW_MASK>(v.n);
   for (int j = 0; j < 3; j++) {
-    o.box.top[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-kFltMax), __float_as_int(v.box.top[j]),
-                                                              CTRL, ROW_MASK, 0xf, false));
-    o.box.bot[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(kFltMax), __float_as_int(v.box.bot[j]),
-                                                              CTRL, ROW_MASK, 0xf, false));
+    o.mx[j] = dpp0<CTRL, ROW_MASK>(v.mx[j]);
+    o.mn[j] = dpp0<CTRL, ROW_MASK>(v.mn[j]);
   }
   combine(v, o);
 }
@@ -369,8 +385,8 @@ __device__ __forceinline__ CountBox last_lane(const CountBox& v) {
   CountBox o;
   o.n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v.n), 63));
   for (int j = 0; j < 3; j++) {
-    o.box.top[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.box.top[j]), 63));
-    o.box.bot[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.box.bot[j]), 63));
+    o.mx[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v.mx[j]), 63));
+    o.mn[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v.mn[j]), 63));
   }
   return o;
 }
@@ -386,7 +402,7 @@ __device__ __forceinline__ void best_step(float& key, uint32_t& idx) {
   }
 }
 
-// `load(b)` returns bin b (b < num_bins).  rb: 6 * num_bins floats of LDS, rb[j * num_bins + b].
+// `load(b)` returns bin b (b < num_bins) as it is stored.  rb: 6 * num_bins words of LDS, rb[j * num_bins + b].
 // All 64 lanes of the wave call this; lane 0 writes *out.
 // LDS written by a wave and read back by the same wave: a block barrier when the block is that one wave
 // (k_bin_sah, k_sah_multi), else the wave's own in-order LDS queue plus a compiler fence (k_subtree)
@@ -401,8 +417,11 @@ __device__ __forceinline__ void wave_lds_sync() {
   }
 }
 
-template <class Load, bool BLOCK = true>
-__device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis, Load load, float* rb, AxisBest* out) {
+// `load_again(s)` reads bin s for the second (left to right) pass; it may leave the bin cleared behind it.
+template <class Load, bool BLOCK = true, class LoadAgain = Load>
+__device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis, Load load, float* rb_f, AxisBest* out,
+                                         LoadAgain load_again) {
+  uint32_t* rb = reinterpret_cast<uint32_t*>(rb_f);
   const int lane = static_cast<int>(threadIdx.x & 63u);
   const uint32_t chunks = (num_bins + 63) / 64;
   // right_bounds[b] = box of bins b .. num_bins-1
@@ -414,8 +433,8 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
     combine(v, carry);
     if (b < num_bins)
       for (int j = 0; j < 3; j++) {
-        rb[j * num_bins + b] = v.box.top[j];
-        rb[(3 + j) * num_bins + b] = v.box.bot[j];
+        rb[j * num_bins + b] = v.mx[j];
+        rb[(3 + j) * num_bins + b] = v.mn[j];
       }
     carry = last_lane(v);
   }
@@ -429,9 +448,8 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
   carry = empty_count_box();
   for (uint32_t c = 0; c < chunks; c++) {
     const uint32_t s = c * 64 + lane;
-    CountBox v = s < num_bins ? load(s) : empty_count_box();
+    CountBox v = s < num_bins ? load_again(s) : empty_count_box();
     wave_scan(v);
-    // carry first, as the sequential loop grows left to right (only the sign of a zero could differ)
     CountBox left = carry;
     combine(left, v);
     if (s + 1 < num_bins) {
@@ -439,16 +457,17 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
       if (left_n > 2 && right_n > 2) {
         Box3 right;
         for (int j = 0; j < 3; j++) {
-          right.top[j] = rb[j * num_bins + s];
-          right.bot[j] = rb[(3 + j) * num_bins + s];
+          right.top[j] = dec_max(rb[j * num_bins + s]);
+          right.bot[j] = dec_min(rb[(3 + j) * num_bins + s]);
         }
-        const float total = cost(left.box.top, left.box.bot, left_n) + cost(right.top, right.bot, right_n);
+        const Box3 lbox = decode(left);
+        const float total = cost(lbox.top, lbox.bot, left_n) + cost(right.top, right.bot, right_n);
         if (total <= kFltMax && !(best_cost < total)) {
           has = true;
           best_cost = total;
           best_index = s;
           best_left_n = left_n;
-          best_left = left.box;
+          best_left = lbox;
           best_right = right;
         }
       }
@@ -489,6 +508,11 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
     for (int i = 0; i < 3; i++) r.ltop[i] = r.lbot[i] = r.rtop[i] = r.rbot[i] = 0.0f;
     *out = r;
   }
+}
+
+template <class Load, bool BLOCK = true>
+__device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis, Load load, float* rb_f, AxisBest* out) {
+  wave_sah<Load, BLOCK, Load>(num_bins, n, axis, load, rb_f, out, load);
 }
 
 // One wave per work item.  Dynamic LDS: per axis held, 7 * num_bins words of bins (count, 3 enc(max),
@@ -589,8 +613,8 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
           CountBox c;
           c.n = bins[b];
           for (int j = 0; j < 3; j++) {
-            c.box.top[j] = dec_max(bins[(1 + j) * num_bins + b]);
-            c.box.bot[j] = dec_min(bins[(4 + j) * num_bins + b]);
+            c.mx[j] = bins[(1 + j) * num_bins + b];
+            c.mn[j] = bins[(4 + j) * num_bins + b];
           }
           return c;
         };
@@ -668,7 +692,10 @@ __global__ void __launch_bounds__(64) k_sah_multi(const Slot* __restrict__ slots
   auto load = [&](uint32_t b) {
     CountBox c;
     c.n = gb[b].count;
-    c.box = load_bin(gb[b]);
+    for (int j = 0; j < 3; j++) {
+      c.mx[j] = gb[b].mx[j];
+      c.mn[j] = gb[b].mn[j];
+    }
     return c;
   };
   wave_sah(num_bins, sl.n, a, load, reinterpret_cast<float*>(lds), &axis_best[s * 3 + a]);
@@ -849,6 +876,7 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
   __shared__ AxisBest s_best[kSmallWaves][3];
   __shared__ uint32_t s_next;
 
+  for (uint32_t b = lane; b < 21 * kSmallBins; b += 64) bins[b] = 0; // this wave's bins; kept clean by wave_sah's second pass
   const SmallRoot R = roots[blockIdx.x];
   const BNode root = top_nodes[R.node];
   const uint32_t n_root = root.end - root.begin;
@@ -892,8 +920,8 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
         }
         const uint32_t num_splits = num_bins - 1;
         if (axis_mask) {
-          for (uint32_t b = lane; b < 21 * num_bins; b += 64) bins[b] = 0;
-          wave_lds_sync<false>();
+          // (the bins are all zero here: cleared once per wave at the start, and by the second pass of wave_sah after
+          // every use)
           for (uint32_t k0 = nd.begin + lane; k0 < nd.end; k0 += 256) {
             uint32_t t[4];
             float4 top[4], bot[4];
@@ -940,12 +968,19 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
             CountBox cb;
             cb.n = ab[b];
             for (int q = 0; q < 3; q++) {
-              cb.box.top[q] = dec_max(ab[(1 + q) * num_bins + b]);
-              cb.box.bot[q] = dec_min(ab[(4 + q) * num_bins + b]);
+              cb.mx[q] = ab[(1 + q) * num_bins + b];
+              cb.mn[q] = ab[(4 + q) * num_bins + b];
             }
             return cb;
           };
-          wave_sah<decltype(load), false>(num_bins, n, a, load, rb, &s_best[wave][a]);
+          uint32_t* abw = bins + a * 7 * num_bins;
+          auto load_and_clear = [&](uint32_t b) { // the last read of a bin leaves it empty for the wave's next node
+            const CountBox cb = load(b);
+            for (int q = 0; q < 7; q++) abw[q * num_bins + b] = 0;
+            return cb;
+          };
+          wave_sah<decltype(load), false, decltype(load_and_clear)>(num_bins, n, a, load, rb, &s_best[wave][a],
+                                                                    load_and_clear);
           wave_lds_sync<false>(); // rb is reused by the next axis
         }
         wave_lds_sync<false>();
