@@ -178,6 +178,11 @@ __global__ void k_root(const uint32_t* __restrict__ root, uint32_t n, BNode* __r
 
 // ---- exclusive scan of u32 (three passes; the block sums of up to 2^24 items fit one block's loop) ----
 constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
+#ifndef NOVA_BVH_MIN_CHUNK
+#define NOVA_BVH_MIN_CHUNK 1024
+#endif
+constexpr uint32_t kMinChunk = NOVA_BVH_MIN_CHUNK; // fewest positions of a k_bin_sah work item
+constexpr uint32_t kFusedLevelNodes = 16384; // levels of at most this many nodes: k_level_setup / k_choose_scan
 
 __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -315,6 +320,65 @@ __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
   }
   slots[s] = sl;
   items[s] = n_items;
+}
+
+// k_level_flags + scan + k_slot_setup + scan of the items in ONE work-group, for the levels of the top of the tree
+// (a few thousand nodes at most): the six launches and two fills this replaces are ~25 us of a ~140 us level.
+// Slots are numbered in node order as the scan of the flags numbers them.
+__global__ void __launch_bounds__(kScanBlock) k_level_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t small,
+                                                            uint32_t num_bins, uint32_t chunk, Slot* __restrict__ slots,
+                                                            uint32_t* __restrict__ item_base, uint32_t* __restrict__ n_slots_out,
+                                                            uint32_t* __restrict__ n_items_out, uint32_t* __restrict__ multi_count,
+                                                            uint32_t* __restrict__ multi_list, uint32_t* __restrict__ multi_items) {
+  if (threadIdx.x == 0) {
+    *multi_count = 0;
+    *multi_items = 0;
+  }
+  __syncthreads();
+  uint32_t slot_carry = 0, item_carry = 0;
+  const float fbins = static_cast<float>(num_bins);
+  for (uint32_t start = 0; start < m; start += kScanBlock) {
+    const uint32_t i = start + threadIdx.x;
+    uint32_t cnt = 0;
+    if (i < m) cnt = nodes[ls + i].end - nodes[ls + i].begin;
+    const bool take = i < m && cnt > kMinTrianglesPerLeaf && cnt > small;
+    const uint32_t n_items = take ? (cnt + chunk - 1) / chunk : 0u;
+    uint32_t slot_total, item_total;
+    const uint32_t s = slot_carry + block_exclusive(take ? 1u : 0u, &slot_total);
+    const uint32_t ib = item_carry + block_exclusive(n_items, &item_total);
+    if (i < m) {
+      BNode& nd = nodes[ls + i];
+      if (!take) {
+        nd.slot = kNone;
+      } else {
+        nd.slot = s;
+        Slot sl;
+        sl.node = ls + i;
+        sl.n = cnt;
+        sl.axis_mask = 0;
+        for (int a = 0; a < 3; a++) {
+          const float step = (nd.top[a] - nd.bot[a]) / fbins; // bvh.cpp:152
+          sl.start[a] = nd.bot[a];
+          sl.inv[a] = 1.0f / step;                            // bvh.cpp:153
+          if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) sl.axis_mask |= 1u << a; // bvh.cpp:169
+        }
+        sl.multi = cnt > chunk ? atomicAdd(multi_count, 1u) : kNone; // which bins it gets does not matter
+        sl.part_base = 0;
+        if (sl.multi != kNone) {
+          multi_list[sl.multi] = s;
+          sl.part_base = atomicAdd(multi_items, n_items);
+        }
+        slots[s] = sl;
+        item_base[s] = ib;
+      }
+    }
+    slot_carry += slot_total;
+    item_carry += item_total;
+  }
+  if (threadIdx.x == 0) {
+    *n_slots_out = slot_carry;
+    *n_items_out = item_carry;
+  }
 }
 
 // bvh.cpp:161-162: min(uvec3((center - bin_start) * inv_bin_step), num_splits)
@@ -733,6 +797,46 @@ __global__ void k_choose(const Slot* __restrict__ slots, const uint32_t* __restr
   split_flag[s] = c.axis >= 0 ? 1u : 0u;
 }
 
+// k_choose and the scan of its flags in one work-group (top of the tree): split_rank[s] = splitting slots before s
+__global__ void __launch_bounds__(kScanBlock) k_choose_scan(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
+                                                            const BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
+                                                            Choice* __restrict__ choice, uint32_t* __restrict__ split_rank,
+                                                            uint32_t* __restrict__ total) {
+  const uint32_t n_slots = *n_slots_ptr;
+  uint32_t carry = 0;
+  for (uint32_t start = 0; start < n_slots; start += kScanBlock) {
+    const uint32_t s = start + threadIdx.x;
+    uint32_t f = 0;
+    if (s < n_slots) {
+      const Slot& sl = slots[s];
+      const BNode& nd = nodes[sl.node];
+      float best_cost = cost(nd.top, nd.bot, sl.n);
+      Choice c;
+      c.axis = -1;
+      c.index = 0;
+      c.left_n = 0;
+      c.child = 0;
+      for (int a = 0; a < 3; a++) {
+        const AxisBest& ab = axis_best[s * 3 + a];
+        if (ab.axis < 0) continue;
+        if (!(best_cost < ab.cost)) {
+          best_cost = ab.cost;
+          c.axis = a;
+          c.index = ab.index;
+          c.left_n = ab.left_n;
+        }
+      }
+      choice[s] = c;
+      f = c.axis >= 0 ? 1u : 0u;
+    }
+    uint32_t sum;
+    const uint32_t ex = carry + block_exclusive(f, &sum);
+    if (s < n_slots) split_rank[s] = ex;
+    carry += sum;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
 // bvh.cpp:107-118: the two child records
 __global__ void k_make_children(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
                                 BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
@@ -766,22 +870,44 @@ __global__ void k_make_children(const Slot* __restrict__ slots, const uint32_t* 
   c.child = child;
 }
 
-// goes_left[k] = 1 when position k moves into the left child (bvh.cpp:120-128)
+// 1 when position k moves into the left child (bvh.cpp:120-128)
+__device__ __forceinline__ uint32_t goes_left_at(uint32_t k, const uint32_t* __restrict__ node_of,
+                                                 const BNode* __restrict__ nodes, uint32_t ls,
+                                                 const Choice* __restrict__ choice, const uint32_t* __restrict__ pbins) {
+  const uint32_t nd = node_of[k];
+  if (nd < ls) return 0u;
+  const uint32_t s = nodes[nd].slot;
+  if (s == kNone) return 0u;
+  const Choice c = choice[s];
+  if (c.axis < 0) return 0u;
+  return ((pbins[k] >> (10 * c.axis)) & 1023u) <= c.index ? 1u : 0u;
+}
 __global__ void k_goes_left(const uint32_t* __restrict__ node_of, uint32_t n, const BNode* __restrict__ nodes,
                             uint32_t ls, const Choice* __restrict__ choice, const uint32_t* __restrict__ pbins,
                             uint32_t* __restrict__ goes_left) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  uint32_t f = 0;
-  const uint32_t nd = node_of[k];
-  if (nd >= ls) {
-    const uint32_t s = nodes[nd].slot;
-    if (s != kNone) {
-      const Choice c = choice[s];
-      if (c.axis >= 0) f = ((pbins[k] >> (10 * c.axis)) & 1023u) <= c.index ? 1u : 0u;
+  goes_left[k] = goes_left_at(k, node_of, nodes, ls, choice, pbins);
+}
+// k_goes_left folded into the first and the last pass of the three-pass scan (k_scan_reduce, k_scan_apply): the flags
+// are also written once, for k_scatter
+__global__ void __launch_bounds__(kScanBlock) k_gl_scan_reduce(const uint32_t* __restrict__ node_of, uint32_t n,
+                                                               const BNode* __restrict__ nodes, uint32_t ls,
+                                                               const Choice* __restrict__ choice,
+                                                               const uint32_t* __restrict__ pbins,
+                                                               uint32_t* __restrict__ goes_left,
+                                                               uint32_t* __restrict__ block_sums) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t s = 0;
+  for (uint32_t j = 0; j < kScanItems; j++)
+    if (base + j < n) {
+      const uint32_t f = goes_left_at(base + j, node_of, nodes, ls, choice, pbins);
+      goes_left[base + j] = f;
+      s += f;
     }
-  }
-  goes_left[k] = f;
+  uint32_t total;
+  (void) block_exclusive(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
 // stable split of every splitting node's segment (left part in order, then right part in order)
@@ -1434,7 +1560,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
       uint32_t chunk = 16 * nb;
       const uint32_t spread = (n / 2048 + 63) & ~63u;
       if (chunk > spread) chunk = spread;
-      if (chunk < 1024) chunk = 1024;
+      if (chunk < kMinChunk) chunk = kMinChunk;
       const uint64_t level_nodes = std::min<uint64_t>(m_bound, 1ull << std::min<uint32_t>(d, 40u));
       const uint64_t mm = std::min<uint64_t>(n / chunk, level_nodes);
       const uint64_t parts = mm ? 2ull * (n / chunk) + 1 : 0;
@@ -1489,11 +1615,15 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     if (num_bins <= 1) break;
     BVHB_TRY(flags.reserve(static_cast<size_t>(m) * 4));
     BVHB_TRY(ranks.reserve(static_cast<size_t>(m) * 4));
-    k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u,
-                                             flags.as<uint32_t>());
-    // the number of nodes to split stays on the device (d_n_slots); the host sizes everything by m
-    int rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>(), d_n_slots);
-    if (rc) return rc;
+    const bool fused_level = m <= kFusedLevelNodes; // the small kernels of a level as two one-group launches
+    int rc = 0;
+    if (!fused_level) {
+      k_level_flags<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u,
+                                               flags.as<uint32_t>());
+      // the number of nodes to split stays on the device (d_n_slots); the host sizes everything by m
+      rc = scan.run(flags.as<uint32_t>(), m, ranks.as<uint32_t>(), d_n_slots);
+      if (rc) return rc;
+    }
     const uint32_t n_slots = m; // upper bound
 
     // work items: `chunk` consecutive positions of one node; a node of more than one item has global bins
@@ -1502,7 +1632,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     uint32_t chunk = 16 * num_bins;
     const uint32_t spread = (n / 2048 + 63) & ~63u;
     if (chunk > spread) chunk = spread;
-    if (chunk < 1024) chunk = 1024;
+    if (chunk < kMinChunk) chunk = kMinChunk;
     const uint32_t max_multi = n / chunk < n_slots ? n / chunk : n_slots; // nodes with more than `chunk` triangles
     const uint32_t max_items = n / chunk + n_slots;
     const uint32_t max_partials = max_multi ? 2 * (n / chunk) + 1 : 0; // ceil(n_s / chunk) <= 2 n_s / chunk for n_s > chunk
@@ -1518,13 +1648,19 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     BVHB_TRY(choice.reserve(static_cast<size_t>(n_slots) * sizeof(Choice)));
     const size_t bin_bytes = n_bins * sizeof(Bin) + static_cast<size_t>(max_partials) * 21 * num_bins * 4;
     peak_bins = bin_bytes > peak_bins ? bin_bytes : peak_bins;
-    BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
-    BVHB_TRY(hipMemsetAsync(items.p, 0, static_cast<size_t>(m) * 4, stream)); // nodes that are not split: no items
-    k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
-                                            num_bins, chunk, slots.as<Slot>(), items.as<uint32_t>(), d_multi_count,
-                                            multi_list.as<uint32_t>(), d_multi_count + 1);
-    rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>(), d_n_items);
-    if (rc) return rc;
+    if (fused_level) {
+      k_level_setup<<<1, kScanBlock, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u, num_bins,
+                                                 chunk, slots.as<Slot>(), item_base.as<uint32_t>(), d_n_slots, d_n_items,
+                                                 d_multi_count, multi_list.as<uint32_t>(), d_multi_count + 1);
+    } else {
+      BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
+      BVHB_TRY(hipMemsetAsync(items.p, 0, static_cast<size_t>(m) * 4, stream)); // nodes that are not split: no items
+      k_slot_setup<<<grid(m), kB, 0, stream>>>(nodes.as<BNode>(), ls, m, flags.as<uint32_t>(), ranks.as<uint32_t>(),
+                                              num_bins, chunk, slots.as<Slot>(), items.as<uint32_t>(), d_multi_count,
+                                              multi_list.as<uint32_t>(), d_multi_count + 1);
+      rc = scan.run(items.as<uint32_t>(), n_slots, item_base.as<uint32_t>(), d_n_items);
+      if (rc) return rc;
+    }
     if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
     if (27 * num_bins * 4 <= 65536) // the bins of three axes and the suffix boxes fit the LDS of one block
       k_bin_sah<true><<<max_items, 64, 27 * num_bins * 4, stream>>>(
@@ -1545,10 +1681,15 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
                                                                   axis_best.as<AxisBest>());
     }
     // flags / ranks are reused per slot from here on (n_slots <= m)
-    k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, n_slots, nodes.as<BNode>(),
-                                              axis_best.as<AxisBest>(), choice.as<Choice>(), flags.as<uint32_t>());
-    rc = scan.run(flags.as<uint32_t>(), n_slots, ranks.as<uint32_t>());
-    if (rc) return rc;
+    if (fused_level) {
+      k_choose_scan<<<1, kScanBlock, 0, stream>>>(slots.as<Slot>(), d_n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
+                                                 choice.as<Choice>(), ranks.as<uint32_t>(), d_total);
+    } else {
+      k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, n_slots, nodes.as<BNode>(),
+                                                axis_best.as<AxisBest>(), choice.as<Choice>(), flags.as<uint32_t>());
+      rc = scan.run(flags.as<uint32_t>(), n_slots, ranks.as<uint32_t>());
+      if (rc) return rc;
+    }
     uint32_t n_split = 0;
     rc = read_total(&n_split);
     if (rc) return rc;
@@ -1557,10 +1698,20 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, nodes.as<BNode>(),
                                                      axis_best.as<AxisBest>(), choice.as<Choice>(),
                                                      ranks.as<uint32_t>(), le);
-    k_goes_left<<<grid(n), kB, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls, choice.as<Choice>(),
-                                           pbins.as<uint32_t>(), gl.as<uint32_t>());
-    rc = scan.run(gl.as<uint32_t>(), n, gls.as<uint32_t>());
-    if (rc) return rc;
+    const uint32_t gl_blocks = (n + kScanTile - 1) / kScanTile;
+    if (gl_blocks > 8) { // the flags are made inside the scan's first pass
+      BVHB_TRY(scan.sums.reserve(static_cast<size_t>(gl_blocks) * 4));
+      k_gl_scan_reduce<<<gl_blocks, kScanBlock, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls,
+                                                            choice.as<Choice>(), pbins.as<uint32_t>(), gl.as<uint32_t>(),
+                                                            scan.sums.as<uint32_t>());
+      k_scan_sums<<<1, kScanBlock, 0, stream>>>(scan.sums.as<uint32_t>(), gl_blocks, d_total);
+      k_scan_apply<<<gl_blocks, kScanBlock, 0, stream>>>(gl.as<uint32_t>(), n, scan.sums.as<uint32_t>(), gls.as<uint32_t>());
+    } else {
+      k_goes_left<<<grid(n), kB, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls, choice.as<Choice>(),
+                                             pbins.as<uint32_t>(), gl.as<uint32_t>());
+      rc = scan.run(gl.as<uint32_t>(), n, gls.as<uint32_t>());
+      if (rc) return rc;
+    }
     k_scatter<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(),
                                          ls, choice.as<Choice>(), gl.as<uint32_t>(), gls.as<uint32_t>(),
                                          order[cur ^ 1].as<uint32_t>(), node_of[cur ^ 1].as<uint32_t>());
