@@ -579,11 +579,14 @@ __device__ __forceinline__ void wave_sah(uint32_t num_bins, uint32_t n, int axis
   wave_sah<Load, BLOCK, Load>(num_bins, n, axis, load, rb_f, out, load);
 }
 
-// One wave per work item.  Dynamic LDS: per axis held, 7 * num_bins words of bins (count, 3 enc(max),
-// 3 ~enc(min), each its own array), then 6 * num_bins floats of suffix boxes.  FUSED: the three axes are
-// binned in one pass over the triangles (21 * num_bins words of bins); otherwise one pass per axis.
+// One work-group of kBinWaves waves per work item (the waves share the item's positions: a wave alone spends the
+// item waiting for its order -> box gathers).  Dynamic LDS: per axis held, 7 * num_bins words of bins (count,
+// 3 enc(max), 3 ~enc(min), each its own array), then per axis held 6 * num_bins words of suffix boxes.  FUSED:
+// the three axes are binned in one pass over the triangles (21 * num_bins words of bins) and, for a node that
+// fits the item, evaluated by three waves side by side; otherwise one pass per axis.
+constexpr uint32_t kBinWaves = 4;
 template <bool FUSED>
-__global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ order, const BNode* __restrict__ nodes,
+__global__ void __launch_bounds__(kBinWaves * 64) k_bin_sah(const uint32_t* __restrict__ order, const BNode* __restrict__ nodes,
                                                 const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
                                                 const uint32_t* __restrict__ item_base,
                                                 const uint32_t* __restrict__ n_items_ptr, uint32_t chunk,
@@ -593,7 +596,9 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
   extern __shared__ uint32_t lds[];
   const uint32_t item = blockIdx.x;
   if (item >= *n_items_ptr) return;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x; // (of the work-group)
+  const uint32_t wave = threadIdx.x >> 6;
+  constexpr uint32_t kT = kBinWaves * 64;
   // the slot whose items include `item`: last s with item_base[s] <= item (every slot has >= 1 item)
   uint32_t lo = 0, hi = *n_slots_ptr - 1;
   while (lo < hi) {
@@ -607,7 +612,7 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
   const uint32_t last = first + chunk < nd.end ? first + chunk : nd.end;
   if (sl.multi != kNone && lane == 0) part_owner[sl.part_base + (item - item_base[s])] = sl.multi;
   constexpr int kHeld = FUSED ? 3 : 1; // axes whose bins are in LDS at once
-  float* rb = reinterpret_cast<float*>(lds + kHeld * 7 * num_bins);
+  float* rb = reinterpret_cast<float*>(lds + kHeld * 7 * num_bins) + (FUSED ? wave : 0u) * 6 * num_bins; // wave a: axis a
   const uint32_t num_splits = num_bins - 1;
 
   auto add = [&](uint32_t* bins, int a, const float4& top, const float4& bot) -> uint32_t {
@@ -627,14 +632,14 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
   for (int pass = 0; pass < (FUSED ? 1 : 3); pass++) {
     const uint32_t pass_mask = FUSED ? sl.axis_mask : (sl.axis_mask & (1u << pass));
     if (pass_mask) {
-      for (uint32_t b = lane; b < kHeld * 7 * num_bins; b += 64) lds[b] = 0;
+      for (uint32_t b = lane; b < kHeld * 7 * num_bins; b += kT) lds[b] = 0;
       __syncthreads();
       // four positions per lane in flight: the order -> box gathers are what this loop waits for
-      for (uint32_t k0 = first + lane; k0 < last; k0 += 256) {
+      for (uint32_t k0 = first + lane; k0 < last; k0 += 4 * kT) {
         uint32_t t[4];
         float4 top[4], bot[4];
         for (int j = 0; j < 4; j++) {
-          const uint32_t k = k0 + 64 * j;
+          const uint32_t k = k0 + kT * j;
           t[j] = k < last ? order[k] : kNone;
         }
         for (int j = 0; j < 4; j++)
@@ -645,7 +650,7 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
         for (int j = 0; j < 4; j++)
           if (t[j] != kNone) {
             // the three bin indices of a position, 10 bits each, for the partition (k_goes_left)
-            const uint32_t k = k0 + 64 * j;
+            const uint32_t k = k0 + kT * j;
             if (FUSED) {
               uint32_t packed = 0;
               for (int a = 0; a < 3; a++)
@@ -682,13 +687,14 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
           }
           return c;
         };
-        wave_sah(num_bins, sl.n, a, load, rb, &axis_best[s * 3 + a]);
-        __syncthreads(); // rb is reused by the next axis
+        // FUSED: wave a evaluates axis a (its own suffix boxes); else the first wave the pass's axis
+        if (wave == (FUSED ? static_cast<uint32_t>(a) : 0u))
+          wave_sah<decltype(load), false>(num_bins, sl.n, a, load, rb, &axis_best[s * 3 + a]);
       } else {
         // this item's bins go to its slab; k_reduce_partials adds the slabs of a node up
         const uint32_t pi = sl.part_base + (item - item_base[s]);
         uint32_t* dst = partials + static_cast<size_t>(pi) * 21 * num_bins + static_cast<size_t>(a) * 7 * num_bins;
-        for (uint32_t b = lane; b < 7 * num_bins; b += 64) dst[b] = bins[b];
+        for (uint32_t b = lane; b < 7 * num_bins; b += kT) dst[b] = bins[b];
       }
     }
     __syncthreads();
@@ -697,7 +703,7 @@ __global__ void __launch_bounds__(64) k_bin_sah(const uint32_t* __restrict__ ord
 
 // Sum of the slabs of every large node into its global bins.  x: the 21 * num_bins words of a slab
 // (axis, field, bin); y: groups of kReduceGroup consecutive slabs, one atomic per word, group and node.
-constexpr uint32_t kReduceGroup = 64;
+constexpr uint32_t kReduceGroup = 32;
 __global__ void k_reduce_partials(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ part_owner,
                                   const uint32_t* __restrict__ n_partials, const Slot* __restrict__ slots,
                                   const uint32_t* __restrict__ multi_list, uint32_t num_bins, Bin* __restrict__ multi_bins) {
@@ -1662,13 +1668,13 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
       if (rc) return rc;
     }
     if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
-    if (27 * num_bins * 4 <= 65536) // the bins of three axes and the suffix boxes fit the LDS of one block
-      k_bin_sah<true><<<max_items, 64, 27 * num_bins * 4, stream>>>(
+    if (39 * num_bins * 4 <= 65536) // the bins of three axes and three sets of suffix boxes fit the LDS of one block
+      k_bin_sah<true><<<max_items, kBinWaves * 64, 39 * num_bins * 4, stream>>>(
         order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
         tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
         axis_best.as<AxisBest>());
     else
-      k_bin_sah<false><<<max_items, 64, 13 * num_bins * 4, stream>>>(
+      k_bin_sah<false><<<max_items, kBinWaves * 64, 13 * num_bins * 4, stream>>>(
         order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
         tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
         axis_best.as<AxisBest>());
