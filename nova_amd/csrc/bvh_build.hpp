@@ -991,6 +991,211 @@ __global__ void k_small_list(const BNode* __restrict__ nodes, uint32_t n_nodes, 
   roots[rank[i]] = { i, d, cap_before[i] };
 }
 
+// ---- nodes of at most 16 triangles, four at a time ---------------------------------------------------------------
+// Half of the inner nodes of a subtree have 9..16 triangles, and a wave that sweeps 48..128 bins for each of them
+// spends ~1300 VALU instructions on it (k_subtree is bound by VALU issue).  Here a wave takes FOUR consecutive
+// nodes of the level, one per row of 16 lanes, a lane per triangle: per axis the lanes of a row are sorted by bin
+// (rank by fifteen row rotations, one ds_permute per value), boxes are scanned from both ends of the row, and a lane
+// whose right neighbour lies in another bin evaluates the split between them — the splits s of wave_sah between
+// two occupied bins all cut the node the same way and cost the same, and the last of them wins there, so that is
+// the index reported.  Same boxes (unsigned max of the encoded words), same cost arithmetic, same tie rules as
+// wave_sah / k_choose, hence the same tree.  Leaves among the four copy their segment.
+constexpr uint32_t kTinyTris = 16;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t old, uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), CTRL, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ void rank_step(uint32_t key, uint32_t& rank) {
+  const uint32_t other = dpp_row<0x120 + K>(key, key); // row_ror:K — the key of lane (l + K) mod 16 of the row
+  rank += other < key ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t row_rank(uint32_t key) { // number of lanes of the row with a smaller key (keys differ)
+  uint32_t rank = 0;
+  rank_step<1>(key, rank); rank_step<2>(key, rank); rank_step<3>(key, rank); rank_step<4>(key, rank);
+  rank_step<5>(key, rank); rank_step<6>(key, rank); rank_step<7>(key, rank); rank_step<8>(key, rank);
+  rank_step<9>(key, rank); rank_step<10>(key, rank); rank_step<11>(key, rank); rank_step<12>(key, rank);
+  rank_step<13>(key, rank); rank_step<14>(key, rank); rank_step<15>(key, rank);
+  return rank;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a < b ? b : a; }
+__device__ __forceinline__ uint32_t lane_get(uint32_t src_lane, uint32_t v) { // v of lane src_lane
+  return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src_lane << 2), static_cast<int>(v)));
+}
+__device__ __forceinline__ uint32_t lane_put(uint32_t dst_lane, uint32_t v) { // this lane's v lands in lane dst_lane
+  return static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(dst_lane << 2), static_cast<int>(v)));
+}
+
+// j: the node of this lane's row (the same in its 16 lanes), of at most kTinyTris triangles, or kNone
+__device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j, uint32_t num_bins, bool may_split,
+                                           const uint32_t* cur, uint32_t* nxt, const float4* __restrict__ tbox,
+                                           uint32_t* s_next, uint32_t lane) {
+  const uint32_t l = lane & 15u, row_base = lane & 48u;
+  const bool have = j != kNone;
+  BNode nd;
+  for (int i = 0; i < 3; i++) nd.top[i] = nd.bot[i] = 0.0f;
+  nd.begin = nd.end = 0;
+  if (have) nd = nodes[j];
+  const uint32_t n = nd.end - nd.begin;
+  const bool mine = have && l < n;                                         // this lane holds a position
+  const bool try_split = have && may_split && n > kMinTrianglesPerLeaf;   // (the same for the row)
+  const uint32_t t = mine ? cur[nd.begin + l] : 0u;
+  if (__ballot(try_split) == 0ull) { // four leaves: their segments stay as they are
+    if (mine) nxt[nd.begin + l] = t;
+    return;
+  }
+  float4 top = make_float4(0.f, 0.f, 0.f, 0.f), bot = top;
+  if (mine && try_split) {
+    top = tbox[2ull * t];
+    bot = tbox[2ull * t + 1];
+  }
+  // k_slot_setup
+  float start[3], inv[3];
+  uint32_t axis_mask = 0;
+  const float fbins = static_cast<float>(num_bins);
+  for (int a = 0; a < 3; a++) {
+    const float step = (nd.top[a] - nd.bot[a]) / fbins;
+    start[a] = nd.bot[a];
+    inv[a] = 1.0f / step;
+    if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) axis_mask |= 1u << a;
+  }
+  const uint32_t num_splits = num_bins - 1;
+  const bool data = mine && try_split;
+  const uint32_t E[6] = { data ? enc(top.x) : 0u, data ? enc(top.y) : 0u, data ? enc(top.z) : 0u,
+                          data ? ~enc(bot.x) : 0u, data ? ~enc(bot.y) : 0u, data ? ~enc(bot.z) : 0u };
+  const uint32_t b3[3] = { bin_index((top.x + bot.x) * 0.5f, start[0], inv[0], num_splits),
+                           bin_index((top.y + bot.y) * 0.5f, start[1], inv[1], num_splits),
+                           bin_index((top.z + bot.z) * 0.5f, start[2], inv[2], num_splits) };
+
+  float best_cost = cost(nd.top, nd.bot, n); // k_choose: the node's own cost first
+  int chosen_axis = -1;
+  uint32_t chosen_index = 0, chosen_pos = 0;
+  uint32_t keep_l[6] = { 0, 0, 0, 0, 0, 0 }, keep_r[6] = { 0, 0, 0, 0, 0, 0 };
+  for (int a = 0; a < 3; a++) {
+    const bool on = data && (axis_mask >> a & 1u);
+    // lanes of the row in bin order (lane number breaks ties; lanes without a triangle last)
+    const uint32_t key = on ? (b3[a] << 4) | l : 0xFFFF0u | l;
+    const uint32_t dst = row_base + row_rank(key);
+    const uint32_t sb = lane_put(dst, on ? b3[a] : 0xFFFFu);
+    uint32_t pre[6], suf[6];
+    for (int i = 0; i < 6; i++) pre[i] = suf[i] = lane_put(dst, on ? E[i] : 0u);
+    // from here on lane l is POSITION l of the sorted row
+    for (int i = 0; i < 6; i++) {
+      pre[i] = umax(pre[i], dpp_row<0x111>(0u, pre[i]));
+      pre[i] = umax(pre[i], dpp_row<0x112>(0u, pre[i]));
+      pre[i] = umax(pre[i], dpp_row<0x114>(0u, pre[i]));
+      pre[i] = umax(pre[i], dpp_row<0x118>(0u, pre[i]));
+      suf[i] = umax(suf[i], dpp_row<0x101>(0u, suf[i]));
+      suf[i] = umax(suf[i], dpp_row<0x102>(0u, suf[i]));
+      suf[i] = umax(suf[i], dpp_row<0x104>(0u, suf[i]));
+      suf[i] = umax(suf[i], dpp_row<0x108>(0u, suf[i]));
+    }
+    // The reference pairs left_bounds[s] with right_bounds[s], whose box still holds bin s (bvh.cpp:77-81).  So the
+    // splits between this lane's bin v and the next occupied bin w come in two kinds: s = v with a right box from
+    // the first triangle of bin v on, and v < s < w (if any) with the right box from bin w on; of the latter the
+    // last one, w - 1, wins their tie.
+    uint32_t right_w[6], right_v[6];
+    for (int i = 0; i < 6; i++) right_w[i] = dpp_row<0x101>(0u, suf[i]); // positions l + 1 ..
+    const uint32_t next_bin = dpp_row<0x101>(0xFFFFu, sb);
+    const uint32_t prev_bin = dpp_row<0x111>(0xFFFFFFFFu, sb);
+    uint32_t first = sb != prev_bin ? l : 0u; // position of the first triangle of this lane's bin: a prefix max
+    first = umax(first, dpp_row<0x111>(0u, first));
+    first = umax(first, dpp_row<0x112>(0u, first));
+    first = umax(first, dpp_row<0x114>(0u, first));
+    first = umax(first, dpp_row<0x118>(0u, first));
+    for (int i = 0; i < 6; i++) right_v[i] = lane_get(row_base + first, suf[i]);
+    const uint32_t left_n = l + 1, right_n = n - left_n;
+    // (n is the row's node's count; the row's axis switch: the same for every lane of the row)
+    const bool axis_on = try_split && (axis_mask >> a & 1u);
+    const bool last_of_bin = axis_on && left_n < n && sb != next_bin && left_n > 2 && right_n > 2;
+    Box3 lb, rv, rw;
+    for (int i = 0; i < 3; i++) {
+      lb.top[i] = dec_max(pre[i]);
+      lb.bot[i] = dec_min(pre[3 + i]);
+      rv.top[i] = dec_max(right_v[i]);
+      rv.bot[i] = dec_min(right_v[3 + i]);
+      rw.top[i] = dec_max(right_w[i]);
+      rw.bot[i] = dec_min(right_w[3 + i]);
+    }
+    const float left_cost = cost(lb.top, lb.bot, left_n);
+    const float total_v = left_cost + cost(rv.top, rv.bot, right_n);
+    const float total_w = left_cost + cost(rw.top, rw.bot, right_n);
+    const bool ok_v = last_of_bin && total_v <= kFltMax;
+    const bool ok_w = last_of_bin && next_bin - 1u > sb && total_w <= kFltMax;
+    const bool use_w = ok_w && !(ok_v && total_v < total_w); // the later split on a tie
+    bool valid = ok_v || ok_w;
+    const float total = use_w ? total_w : total_v;
+    const uint32_t my_index = use_w ? next_bin - 1u : sb;
+    uint32_t right[6];
+    for (int i = 0; i < 6; i++) right[i] = use_w ? right_w[i] : right_v[i];
+    // smallest cost, the later split on a tie: lane 15 of the row ends up with the best of the row
+    float key_cost = valid ? total : __builtin_inff();
+    uint32_t idx = valid ? my_index : 0u;
+    best_step<0x111, 0xf>(key_cost, idx);
+    best_step<0x112, 0xf>(key_cost, idx);
+    best_step<0x114, 0xf>(key_cost, idx);
+    best_step<0x118, 0xf>(key_cost, idx);
+    const float row_cost = __uint_as_float(lane_get(row_base + 15u, __float_as_uint(key_cost)));
+    const uint32_t row_index = lane_get(row_base + 15u, idx);
+    const bool winner = valid && total == row_cost && my_index == row_index;
+    const uint32_t wmask = static_cast<uint32_t>((__ballot(winner) >> row_base) & 0xFFFFull);
+    // k_choose: the later axis wins a tie
+    if (wmask != 0u && !(best_cost < row_cost)) {
+      best_cost = row_cost;
+      chosen_axis = a;
+      chosen_index = row_index;
+      chosen_pos = static_cast<uint32_t>(__builtin_ctz(wmask));
+      for (int i = 0; i < 6; i++) {
+        keep_l[i] = pre[i];
+        keep_r[i] = right[i];
+      }
+    }
+  }
+  // the winner's boxes to the whole row (its first lane writes the records)
+  const uint32_t wl = row_base + chosen_pos;
+  uint32_t wbox_l[6], wbox_r[6];
+  for (int i = 0; i < 6; i++) {
+    wbox_l[i] = lane_get(wl, keep_l[i]);
+    wbox_r[i] = lane_get(wl, keep_r[i]);
+  }
+  const bool split = chosen_axis >= 0;
+  const uint32_t left_count = chosen_pos + 1;
+  uint32_t child = 0;
+  if (split && l == 0) child = atomicAdd(s_next, 2u);
+  child = lane_get(row_base, child);
+  if (split && l == 0) {
+    BNode lc, rc;
+    for (int i = 0; i < 3; i++) {
+      lc.top[i] = dec_max(wbox_l[i]);
+      lc.bot[i] = dec_min(wbox_l[3 + i]);
+      rc.top[i] = dec_max(wbox_r[i]);
+      rc.bot[i] = dec_min(wbox_r[3 + i]);
+    }
+    lc.begin = nd.begin;
+    lc.end = nd.begin + left_count;
+    rc.begin = lc.end;
+    rc.end = nd.end;
+    lc.left = lc.right = rc.left = rc.right = 0;
+    lc.slot = rc.slot = kNone;
+    lc.size = rc.size = 1;
+    nodes[child] = lc;
+    nodes[child + 1] = rc;
+    nodes[j].left = child;
+    nodes[j].right = child + 1;
+  }
+  // stable split of the row's segment (lanes are in position order again), or the segment as it is
+  const uint32_t my_bin = chosen_axis == 0 ? b3[0] : (chosen_axis == 1 ? b3[1] : b3[2]);
+  const bool goes_left = mine && split && my_bin <= chosen_index;
+  const bool goes_right = mine && split && !goes_left;
+  const uint32_t below = (1u << l) - 1u;
+  const uint32_t ml = static_cast<uint32_t>((__ballot(goes_left) >> row_base) & 0xFFFFull);
+  const uint32_t mr = static_cast<uint32_t>((__ballot(goes_right) >> row_base) & 0xFFFFull);
+  if (goes_left) nxt[nd.begin + static_cast<uint32_t>(__popc(ml & below))] = t;
+  else if (goes_right) nxt[nd.begin + left_count + static_cast<uint32_t>(__popc(mr & below))] = t;
+  else if (mine) nxt[nd.begin + l] = t;
+}
+
 // Dynamic LDS: ord[2][kSmallTris], pb[kSmallTris], per wave 27 * kSmallBins words (bins of three axes + suffix boxes)
 __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
     const SmallRoot* __restrict__ roots, const BNode* __restrict__ top_nodes, const float4* __restrict__ tbox,
@@ -1033,7 +1238,7 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
     const uint32_t depth = R.depth + l;
     const uint32_t num_bins = static_cast<uint32_t>(kMaxBins / static_cast<float>(depth + 1)); // bvh.cpp:145
     const bool may_split = num_bins > 1;
-    for (uint32_t j = lvl_begin + wave; j < lvl_end; j += kSmallWaves) {
+    auto big_node = [&](uint32_t j) {
       const BNode nd = nodes[j];
       const uint32_t n = nd.end - nd.begin;
       Choice c;
@@ -1170,6 +1375,42 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
         }
       } else {
         for (uint32_t k = nd.begin + lane; k < nd.end; k += 64) nxt[k] = cur[k]; // a leaf: its segment stays
+      }
+    };
+    // A wave takes up to 64 consecutive nodes of the level at a time, a lane per node: those of more than 16 triangles
+    // one after the other by the whole wave (big_node), the others four at a time, one per row of lanes
+    // (tiny_nodes) — the ones that may split first, so that their turns have all four rows at work and the
+    // turns of the leaves that remain cost a copy.
+    // (a short level is dealt to all the waves: `per` nodes at a time, at most 64)
+    const uint32_t per_wave = (lvl_end - lvl_begin + kSmallWaves - 1) / kSmallWaves;
+    const uint32_t per = per_wave < 64u ? per_wave : 64u;
+    for (uint32_t j0 = lvl_begin + per * wave; j0 < lvl_end; j0 += per * kSmallWaves) {
+      const uint32_t jn = j0 + lane;
+      const bool in_turn = lane < per && jn < lvl_end;
+      uint32_t cnt = 0;
+      if (in_turn) cnt = nodes[jn].end - nodes[jn].begin;
+      const bool is_big = in_turn && cnt > kTinyTris;
+      const bool is_tiny = in_turn && !is_big && may_split && cnt > kMinTrianglesPerLeaf;
+      const bool is_leaf = in_turn && !is_big && !is_tiny;
+      const uint64_t m_tiny = __ballot(is_tiny), m_leaf = __ballot(is_leaf);
+      uint64_t m_big = __ballot(is_big);
+      const uint64_t below = (1ull << lane) - 1ull;
+      const uint32_t n_tiny = static_cast<uint32_t>(__popcll(m_tiny)), n_small = n_tiny + static_cast<uint32_t>(__popcll(m_leaf));
+      // lane k of `list` = the k-th of them: the splittable ones, then the leaves
+      const uint32_t slot = is_tiny ? static_cast<uint32_t>(__popcll(m_tiny & below))
+                                    : n_tiny + static_cast<uint32_t>(__popcll(m_leaf & below));
+      const uint32_t list = lane_put((is_tiny || is_leaf) ? slot : 63u, (is_tiny || is_leaf) ? jn : kNone);
+      // (lanes that hold neither send to lane 63, which is only read when all 64 nodes are small — and then
+      // nobody sends there but its rightful owner)
+      for (uint32_t g = 0; g < n_small; g += 4) {
+        const uint32_t k = g + (lane >> 4);
+        const uint32_t j = lane_get(k < n_small ? k : 0u, list);
+        tiny_nodes(nodes, k < n_small ? j : kNone, num_bins, may_split, cur, nxt, tbox, &s_next, lane);
+      }
+      while (m_big) {
+        const uint32_t r = static_cast<uint32_t>(__builtin_ctzll(m_big));
+        m_big &= m_big - 1ull;
+        big_node(j0 + r);
       }
     }
     __threadfence_block();
