@@ -182,7 +182,7 @@ constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kS
 #define NOVA_BVH_MIN_CHUNK 1024
 #endif
 constexpr uint32_t kMinChunk = NOVA_BVH_MIN_CHUNK; // fewest positions of a k_bin_sah work item
-constexpr uint32_t kFusedLevelNodes = 16384; // levels of at most this many nodes: k_level_setup / k_choose_scan
+constexpr uint32_t kFusedLevelNodes = 2048; // levels of at most this many nodes: k_level_setup / k_choose_scan
 
 __device__ __forceinline__ uint32_t wave_inclusive(uint32_t v) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -223,13 +223,21 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_reduce(const uint32_t* __re
 // one block: block_sums -> exclusive prefix in place; grand total to *total
 __global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
                                                            uint32_t* __restrict__ total) {
+  constexpr uint32_t kPer = 16; // consecutive sums per thread and round (10 M triangles: 9766 sums, 3 rounds)
   uint32_t carry = 0;
-  for (uint32_t start = 0; start < nb; start += kScanBlock) {
-    const uint32_t i = start + threadIdx.x;
-    const uint32_t v = i < nb ? block_sums[i] : 0u;
+  for (uint32_t start = 0; start < nb; start += kScanBlock * kPer) {
+    const uint32_t base = start + threadIdx.x * kPer;
+    uint32_t v[kPer], s = 0;
+    for (uint32_t j = 0; j < kPer; j++) {
+      v[j] = base + j < nb ? block_sums[base + j] : 0u;
+      s += v[j];
+    }
     uint32_t sum;
-    const uint32_t ex = block_exclusive(v, &sum);
-    if (i < nb) block_sums[i] = carry + ex;
+    uint32_t ex = carry + block_exclusive(s, &sum);
+    for (uint32_t j = 0; j < kPer; j++) {
+      if (base + j < nb) block_sums[base + j] = ex;
+      ex += v[j];
+    }
     carry += sum;
   }
   if (threadIdx.x == 0) *total = carry;
