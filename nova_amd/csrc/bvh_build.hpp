@@ -1009,22 +1009,26 @@ __global__ void k_small_list(const BNode* __restrict__ nodes, uint32_t n_nodes, 
 // the index reported.  Same boxes (unsigned max of the encoded words), same cost arithmetic, same tie rules as
 // wave_sah / k_choose, hence the same tree.  Leaves among the four copy their segment.
 constexpr uint32_t kTinyTris = 16;
+constexpr uint32_t kMidTris = 32; // two nodes per wave, one per half: the same with two rows per node
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_row(uint32_t old, uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), CTRL, 0xf, 0xf, false));
 }
 template <int K>
-__device__ __forceinline__ void rank_step(uint32_t key, uint32_t& rank) {
-  const uint32_t other = dpp_row<0x120 + K>(key, key); // row_ror:K — the key of lane (l + K) mod 16 of the row
-  rank += other < key ? 1u : 0u;
+__device__ __forceinline__ void rank_step(uint32_t mine, uint32_t theirs, uint32_t& rank) {
+  const uint32_t other = dpp_row<0x120 + K>(theirs, theirs); // row_ror:K — `theirs` of lane (l + K) mod 16 of the row
+  rank += other < mine ? 1u : 0u;
 }
-__device__ __forceinline__ uint32_t row_rank(uint32_t key) { // number of lanes of the row with a smaller key (keys differ)
-  uint32_t rank = 0;
-  rank_step<1>(key, rank); rank_step<2>(key, rank); rank_step<3>(key, rank); rank_step<4>(key, rank);
-  rank_step<5>(key, rank); rank_step<6>(key, rank); rank_step<7>(key, rank); rank_step<8>(key, rank);
-  rank_step<9>(key, rank); rank_step<10>(key, rank); rank_step<11>(key, rank); rank_step<12>(key, rank);
-  rank_step<13>(key, rank); rank_step<14>(key, rank); rank_step<15>(key, rank);
+// number of lanes of the row whose `theirs` is smaller than this lane's `mine` (lane l itself included when SELF)
+template <bool SELF>
+__device__ __forceinline__ uint32_t row_rank(uint32_t mine, uint32_t theirs) {
+  uint32_t rank = (SELF && theirs < mine) ? 1u : 0u;
+  rank_step<1>(mine, theirs, rank); rank_step<2>(mine, theirs, rank); rank_step<3>(mine, theirs, rank);
+  rank_step<4>(mine, theirs, rank); rank_step<5>(mine, theirs, rank); rank_step<6>(mine, theirs, rank);
+  rank_step<7>(mine, theirs, rank); rank_step<8>(mine, theirs, rank); rank_step<9>(mine, theirs, rank);
+  rank_step<10>(mine, theirs, rank); rank_step<11>(mine, theirs, rank); rank_step<12>(mine, theirs, rank);
+  rank_step<13>(mine, theirs, rank); rank_step<14>(mine, theirs, rank); rank_step<15>(mine, theirs, rank);
   return rank;
 }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a < b ? b : a; }
@@ -1034,12 +1038,56 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t src_lane, uint32_t v) { //
 __device__ __forceinline__ uint32_t lane_put(uint32_t dst_lane, uint32_t v) { // this lane's v lands in lane dst_lane
   return static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(dst_lane << 2), static_cast<int>(v)));
 }
+// inclusive max scans over the G (16: a row, 32: two rows) lanes of a group; 0 is the identity
+template <int G>
+__device__ __forceinline__ uint32_t group_prefix_max(uint32_t v) {
+  v = umax(v, dpp_row<0x111>(0u, v));
+  v = umax(v, dpp_row<0x112>(0u, v));
+  v = umax(v, dpp_row<0x114>(0u, v));
+  v = umax(v, dpp_row<0x118>(0u, v));
+  if (G == 32) v = umax(v, dpp0<0x142, 0xa>(v)); // lane 15 of the lower row into the upper row
+  return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_suffix_max(uint32_t v, uint32_t lane) {
+  v = umax(v, dpp_row<0x101>(0u, v));
+  v = umax(v, dpp_row<0x102>(0u, v));
+  v = umax(v, dpp_row<0x104>(0u, v));
+  v = umax(v, dpp_row<0x108>(0u, v));
+  if (G == 32) {
+    const uint32_t upper = lane_get((lane & 32u) + 16u, v); // everything of the upper row
+    if ((lane & 16u) == 0u) v = umax(v, upper);
+  }
+  return v;
+}
+// the value of the next / the previous lane of the group (`edge` beyond it)
+template <int G>
+__device__ __forceinline__ uint32_t group_next(uint32_t v, uint32_t edge, uint32_t lane) {
+  uint32_t r = dpp_row<0x101>(edge, v);
+  if (G == 32) {
+    const uint32_t first_upper = lane_get((lane & 32u) + 16u, v);
+    if ((lane & 31u) == 15u) r = first_upper;
+  }
+  return r;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_prev(uint32_t v, uint32_t edge, uint32_t lane) {
+  uint32_t r = dpp_row<0x111>(edge, v);
+  if (G == 32) {
+    const uint32_t last_lower = lane_get((lane & 32u) + 15u, v);
+    if ((lane & 31u) == 16u) r = last_lower;
+  }
+  return r;
+}
 
-// j: the node of this lane's row (the same in its 16 lanes), of at most kTinyTris triangles, or kNone
+// j: the node of this lane's group (the same in its G lanes), of at most G triangles, or kNone
+template <int G>
 __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j, uint32_t num_bins, bool may_split,
                                            const uint32_t* cur, uint32_t* nxt, const float4* __restrict__ tbox,
                                            uint32_t* s_next, uint32_t lane) {
-  const uint32_t l = lane & 15u, row_base = lane & 48u;
+  static_assert(G == 16 || G == 32, "a row or two");
+  constexpr uint32_t kGroupMask = G == 32 ? 0xFFFFFFFFu : 0xFFFFu;
+  const uint32_t l = lane & (G - 1u), row_base = lane & (64u - G);
   const bool have = j != kNone;
   BNode nd;
   for (int i = 0; i < 3; i++) nd.top[i] = nd.bot[i] = 0.0f;
@@ -1047,9 +1095,9 @@ __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j
   if (have) nd = nodes[j];
   const uint32_t n = nd.end - nd.begin;
   const bool mine = have && l < n;                                         // this lane holds a position
-  const bool try_split = have && may_split && n > kMinTrianglesPerLeaf;   // (the same for the row)
+  const bool try_split = have && may_split && n > kMinTrianglesPerLeaf;   // (the same for the group)
   const uint32_t t = mine ? cur[nd.begin + l] : 0u;
-  if (__ballot(try_split) == 0ull) { // four leaves: their segments stay as they are
+  if (__ballot(try_split) == 0ull) { // leaves only: their segments stay as they are
     if (mine) nxt[nd.begin + l] = t;
     return;
   }
@@ -1082,39 +1130,31 @@ __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j
   uint32_t keep_l[6] = { 0, 0, 0, 0, 0, 0 }, keep_r[6] = { 0, 0, 0, 0, 0, 0 };
   for (int a = 0; a < 3; a++) {
     const bool on = data && (axis_mask >> a & 1u);
-    // lanes of the row in bin order (lane number breaks ties; lanes without a triangle last)
-    const uint32_t key = on ? (b3[a] << 4) | l : 0xFFFF0u | l;
-    const uint32_t dst = row_base + row_rank(key);
+    // lanes of the group in bin order (lane number breaks ties; lanes without a triangle last)
+    const uint32_t key = on ? (b3[a] << 5) | l : 0xFFFF00u | l;
+    uint32_t rank = row_rank<false>(key, key);
+    if (G == 32) rank += row_rank<true>(key, lane_get(lane ^ 16u, key)); // ... and the keys of the other row
+    const uint32_t dst = row_base + rank;
     const uint32_t sb = lane_put(dst, on ? b3[a] : 0xFFFFu);
     uint32_t pre[6], suf[6];
-    for (int i = 0; i < 6; i++) pre[i] = suf[i] = lane_put(dst, on ? E[i] : 0u);
-    // from here on lane l is POSITION l of the sorted row
     for (int i = 0; i < 6; i++) {
-      pre[i] = umax(pre[i], dpp_row<0x111>(0u, pre[i]));
-      pre[i] = umax(pre[i], dpp_row<0x112>(0u, pre[i]));
-      pre[i] = umax(pre[i], dpp_row<0x114>(0u, pre[i]));
-      pre[i] = umax(pre[i], dpp_row<0x118>(0u, pre[i]));
-      suf[i] = umax(suf[i], dpp_row<0x101>(0u, suf[i]));
-      suf[i] = umax(suf[i], dpp_row<0x102>(0u, suf[i]));
-      suf[i] = umax(suf[i], dpp_row<0x104>(0u, suf[i]));
-      suf[i] = umax(suf[i], dpp_row<0x108>(0u, suf[i]));
+      const uint32_t v = lane_put(dst, on ? E[i] : 0u);
+      // from here on lane l is POSITION l of the sorted group
+      pre[i] = group_prefix_max<G>(v);
+      suf[i] = group_suffix_max<G>(v, lane);
     }
     // The reference pairs left_bounds[s] with right_bounds[s], whose box still holds bin s (bvh.cpp:77-81).  So the
     // splits between this lane's bin v and the next occupied bin w come in two kinds: s = v with a right box from
     // the first triangle of bin v on, and v < s < w (if any) with the right box from bin w on; of the latter the
     // last one, w - 1, wins their tie.
     uint32_t right_w[6], right_v[6];
-    for (int i = 0; i < 6; i++) right_w[i] = dpp_row<0x101>(0u, suf[i]); // positions l + 1 ..
-    const uint32_t next_bin = dpp_row<0x101>(0xFFFFu, sb);
-    const uint32_t prev_bin = dpp_row<0x111>(0xFFFFFFFFu, sb);
-    uint32_t first = sb != prev_bin ? l : 0u; // position of the first triangle of this lane's bin: a prefix max
-    first = umax(first, dpp_row<0x111>(0u, first));
-    first = umax(first, dpp_row<0x112>(0u, first));
-    first = umax(first, dpp_row<0x114>(0u, first));
-    first = umax(first, dpp_row<0x118>(0u, first));
+    for (int i = 0; i < 6; i++) right_w[i] = group_next<G>(suf[i], 0u, lane); // positions l + 1 ..
+    const uint32_t next_bin = group_next<G>(sb, 0xFFFFu, lane);
+    const uint32_t prev_bin = group_prev<G>(sb, 0xFFFFFFFFu, lane);
+    const uint32_t first = group_prefix_max<G>(sb != prev_bin ? l : 0u); // position of the first triangle of this lane's bin
     for (int i = 0; i < 6; i++) right_v[i] = lane_get(row_base + first, suf[i]);
     const uint32_t left_n = l + 1, right_n = n - left_n;
-    // (n is the row's node's count; the row's axis switch: the same for every lane of the row)
+    // (n is the group's node's count; the group's axis switch: the same for every lane of the group)
     const bool axis_on = try_split && (axis_mask >> a & 1u);
     const bool last_of_bin = axis_on && left_n < n && sb != next_bin && left_n > 2 && right_n > 2;
     Box3 lb, rv, rw;
@@ -1132,22 +1172,23 @@ __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j
     const bool ok_v = last_of_bin && total_v <= kFltMax;
     const bool ok_w = last_of_bin && next_bin - 1u > sb && total_w <= kFltMax;
     const bool use_w = ok_w && !(ok_v && total_v < total_w); // the later split on a tie
-    bool valid = ok_v || ok_w;
+    const bool valid = ok_v || ok_w;
     const float total = use_w ? total_w : total_v;
     const uint32_t my_index = use_w ? next_bin - 1u : sb;
     uint32_t right[6];
     for (int i = 0; i < 6; i++) right[i] = use_w ? right_w[i] : right_v[i];
-    // smallest cost, the later split on a tie: lane 15 of the row ends up with the best of the row
+    // smallest cost, the later split on a tie: the last lane of the group ends up with the best of the group
     float key_cost = valid ? total : __builtin_inff();
     uint32_t idx = valid ? my_index : 0u;
     best_step<0x111, 0xf>(key_cost, idx);
     best_step<0x112, 0xf>(key_cost, idx);
     best_step<0x114, 0xf>(key_cost, idx);
     best_step<0x118, 0xf>(key_cost, idx);
-    const float row_cost = __uint_as_float(lane_get(row_base + 15u, __float_as_uint(key_cost)));
-    const uint32_t row_index = lane_get(row_base + 15u, idx);
+    if (G == 32) best_step<0x142, 0xa>(key_cost, idx);
+    const float row_cost = __uint_as_float(lane_get(row_base + (G - 1u), __float_as_uint(key_cost)));
+    const uint32_t row_index = lane_get(row_base + (G - 1u), idx);
     const bool winner = valid && total == row_cost && my_index == row_index;
-    const uint32_t wmask = static_cast<uint32_t>((__ballot(winner) >> row_base) & 0xFFFFull);
+    const uint32_t wmask = static_cast<uint32_t>((__ballot(winner) >> row_base) & kGroupMask);
     // k_choose: the later axis wins a tie
     if (wmask != 0u && !(best_cost < row_cost)) {
       best_cost = row_cost;
@@ -1160,7 +1201,7 @@ __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j
       }
     }
   }
-  // the winner's boxes to the whole row (its first lane writes the records)
+  // the winner's boxes to the whole group (its first lane writes the records)
   const uint32_t wl = row_base + chosen_pos;
   uint32_t wbox_l[6], wbox_r[6];
   for (int i = 0; i < 6; i++) {
@@ -1192,13 +1233,13 @@ __device__ __forceinline__ void tiny_nodes(BNode* __restrict__ nodes, uint32_t j
     nodes[j].left = child;
     nodes[j].right = child + 1;
   }
-  // stable split of the row's segment (lanes are in position order again), or the segment as it is
+  // stable split of the group's segment (lanes are in position order again), or the segment as it is
   const uint32_t my_bin = chosen_axis == 0 ? b3[0] : (chosen_axis == 1 ? b3[1] : b3[2]);
   const bool goes_left = mine && split && my_bin <= chosen_index;
   const bool goes_right = mine && split && !goes_left;
   const uint32_t below = (1u << l) - 1u;
-  const uint32_t ml = static_cast<uint32_t>((__ballot(goes_left) >> row_base) & 0xFFFFull);
-  const uint32_t mr = static_cast<uint32_t>((__ballot(goes_right) >> row_base) & 0xFFFFull);
+  const uint32_t ml = static_cast<uint32_t>((__ballot(goes_left) >> row_base) & kGroupMask);
+  const uint32_t mr = static_cast<uint32_t>((__ballot(goes_right) >> row_base) & kGroupMask);
   if (goes_left) nxt[nd.begin + static_cast<uint32_t>(__popc(ml & below))] = t;
   else if (goes_right) nxt[nd.begin + left_count + static_cast<uint32_t>(__popc(mr & below))] = t;
   else if (mine) nxt[nd.begin + l] = t;
@@ -1385,10 +1426,10 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
         for (uint32_t k = nd.begin + lane; k < nd.end; k += 64) nxt[k] = cur[k]; // a leaf: its segment stays
       }
     };
-    // A wave takes up to 64 consecutive nodes of the level at a time, a lane per node: those of more than 16 triangles
-    // one after the other by the whole wave (big_node), the others four at a time, one per row of lanes
-    // (tiny_nodes) — the ones that may split first, so that their turns have all four rows at work and the
-    // turns of the leaves that remain cost a copy.
+    // A wave takes up to 64 consecutive nodes of the level at a time, a lane per node: those of more than 32 triangles
+    // one after the other by the whole wave (big_node), those of 17..32 two at a time, the others four at a time, one
+    // per row of lanes (tiny_nodes) — the ones that may split first, so that their turns have all four rows at work
+    // and the turns of the leaves that remain cost a copy.
     // (a short level is dealt to all the waves: `per` nodes at a time, at most 64)
     const uint32_t per_wave = (lvl_end - lvl_begin + kSmallWaves - 1) / kSmallWaves;
     const uint32_t per = per_wave < 64u ? per_wave : 64u;
@@ -1397,23 +1438,31 @@ __global__ void __launch_bounds__(kSmallWaves * 64) k_subtree(
       const bool in_turn = lane < per && jn < lvl_end;
       uint32_t cnt = 0;
       if (in_turn) cnt = nodes[jn].end - nodes[jn].begin;
-      const bool is_big = in_turn && cnt > kTinyTris;
-      const bool is_tiny = in_turn && !is_big && may_split && cnt > kMinTrianglesPerLeaf;
-      const bool is_leaf = in_turn && !is_big && !is_tiny;
-      const uint64_t m_tiny = __ballot(is_tiny), m_leaf = __ballot(is_leaf);
+      const bool is_big = in_turn && cnt > kMidTris;
+      const bool is_mid = in_turn && !is_big && cnt > kTinyTris;
+      const bool is_tiny = in_turn && !is_big && !is_mid && may_split && cnt > kMinTrianglesPerLeaf;
+      const bool is_leaf = in_turn && !is_big && !is_mid && !is_tiny;
+      const uint64_t m_tiny = __ballot(is_tiny), m_leaf = __ballot(is_leaf), m_mid = __ballot(is_mid);
       uint64_t m_big = __ballot(is_big);
       const uint64_t below = (1ull << lane) - 1ull;
       const uint32_t n_tiny = static_cast<uint32_t>(__popcll(m_tiny)), n_small = n_tiny + static_cast<uint32_t>(__popcll(m_leaf));
-      // lane k of `list` = the k-th of them: the splittable ones, then the leaves
-      const uint32_t slot = is_tiny ? static_cast<uint32_t>(__popcll(m_tiny & below))
-                                    : n_tiny + static_cast<uint32_t>(__popcll(m_leaf & below));
-      const uint32_t list = lane_put((is_tiny || is_leaf) ? slot : 63u, (is_tiny || is_leaf) ? jn : kNone);
-      // (lanes that hold neither send to lane 63, which is only read when all 64 nodes are small — and then
-      // nobody sends there but its rightful owner)
+      const uint32_t n_mid = static_cast<uint32_t>(__popcll(m_mid));
+      // lane k of `list` = the k-th of the small ones: the splittable ones, then the leaves; lane 63 - k = the k-th
+      // of 17..32 triangles (a lane that holds none of these sends nothing anyone reads: the two lists meet at most)
+      uint32_t slot = 63u - n_mid; // (a free lane between the lists, or — 64 nodes, all listed — nobody sends here)
+      if (is_tiny) slot = static_cast<uint32_t>(__popcll(m_tiny & below));
+      else if (is_leaf) slot = n_tiny + static_cast<uint32_t>(__popcll(m_leaf & below));
+      else if (is_mid) slot = 63u - static_cast<uint32_t>(__popcll(m_mid & below));
+      const uint32_t list = lane_put(slot, (is_tiny || is_leaf || is_mid) ? jn : kNone);
       for (uint32_t g = 0; g < n_small; g += 4) {
         const uint32_t k = g + (lane >> 4);
         const uint32_t j = lane_get(k < n_small ? k : 0u, list);
-        tiny_nodes(nodes, k < n_small ? j : kNone, num_bins, may_split, cur, nxt, tbox, &s_next, lane);
+        tiny_nodes<16>(nodes, k < n_small ? j : kNone, num_bins, may_split, cur, nxt, tbox, &s_next, lane);
+      }
+      for (uint32_t g = 0; g < n_mid; g += 2) {
+        const uint32_t k = g + (lane >> 5);
+        const uint32_t j = lane_get(k < n_mid ? 63u - k : 0u, list);
+        tiny_nodes<32>(nodes, k < n_mid ? j : kNone, num_bins, may_split, cur, nxt, tbox, &s_next, lane);
       }
       while (m_big) {
         const uint32_t r = static_cast<uint32_t>(__builtin_ctzll(m_big));
