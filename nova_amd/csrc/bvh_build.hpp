@@ -333,8 +333,9 @@ __global__ void k_slot_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m,
 // k_level_flags + scan + k_slot_setup + scan of the items in ONE work-group, for the levels of the top of the tree
 // (a few thousand nodes at most): the six launches and two fills this replaces are ~25 us of a ~140 us level.
 // Slots are numbered in node order as the scan of the flags numbers them.
+// all_multi: every splitting node gets global bins and slabs, whatever its size (the two topmost levels: see build())
 __global__ void __launch_bounds__(kScanBlock) k_level_setup(BNode* __restrict__ nodes, uint32_t ls, uint32_t m, uint32_t small,
-                                                            uint32_t num_bins, uint32_t chunk, Slot* __restrict__ slots,
+                                                            uint32_t num_bins, uint32_t chunk, bool all_multi, Slot* __restrict__ slots,
                                                             uint32_t* __restrict__ item_base, uint32_t* __restrict__ n_slots_out,
                                                             uint32_t* __restrict__ n_items_out, uint32_t* __restrict__ multi_count,
                                                             uint32_t* __restrict__ multi_list, uint32_t* __restrict__ multi_items) {
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(kScanBlock) k_level_setup(BNode* __restrict__ 
           sl.inv[a] = 1.0f / step;                            // bvh.cpp:153
           if (!(fabsf(nd.top[a] - nd.bot[a]) < 1e-4f)) sl.axis_mask |= 1u << a; // bvh.cpp:169
         }
-        sl.multi = cnt > chunk ? atomicAdd(multi_count, 1u) : kNone; // which bins it gets does not matter
+        sl.multi = (cnt > chunk || all_multi) ? atomicAdd(multi_count, 1u) : kNone; // which bins it gets does not matter
         sl.part_base = 0;
         if (sl.multi != kNone) {
           multi_list[sl.multi] = s;
@@ -1866,8 +1867,9 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
       if (chunk > spread) chunk = spread;
       if (chunk < kMinChunk) chunk = kMinChunk;
       const uint64_t level_nodes = std::min<uint64_t>(m_bound, 1ull << std::min<uint32_t>(d, 40u));
-      const uint64_t mm = std::min<uint64_t>(n / chunk, level_nodes);
-      const uint64_t parts = mm ? 2ull * (n / chunk) + 1 : 0;
+      const bool all_multi = 39ull * nb * 4 > 65536; // as in the level loop
+      const uint64_t mm = all_multi ? level_nodes : std::min<uint64_t>(n / chunk, level_nodes);
+      const uint64_t parts = mm ? 2ull * (n / chunk) + 1 + (all_multi ? level_nodes : 0) : 0;
       max_part = std::max<size_t>(max_part, parts * 21 * nb * 4 + 16);
       max_owner = std::max<size_t>(max_owner, parts * 4 + 16);
       max_bins = std::max<size_t>(max_bins, mm * 3 * nb * sizeof(Bin) + 16);
@@ -1937,9 +1939,15 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     const uint32_t spread = (n / 2048 + 63) & ~63u;
     if (chunk > spread) chunk = spread;
     if (chunk < kMinChunk) chunk = kMinChunk;
-    const uint32_t max_multi = n / chunk < n_slots ? n / chunk : n_slots; // nodes with more than `chunk` triangles
+    // The two topmost levels have too many bins for a work item to hold three axes of them AND the suffix boxes an
+    // evaluation on the spot needs (39 * num_bins words of LDS).  Binning one axis per pass (k_bin_sah<false>) reads
+    // every triangle three times; instead every node of such a level is treated like one of several items: three
+    // axes in one pass (21 * num_bins words), slabs, evaluation from the global bins.
+    const bool all_multi = fused_level && 39ull * num_bins * 4 > 65536;
+    const uint32_t max_multi = all_multi ? n_slots : (n / chunk < n_slots ? n / chunk : n_slots); // nodes with global bins
     const uint32_t max_items = n / chunk + n_slots;
-    const uint32_t max_partials = max_multi ? 2 * (n / chunk) + 1 : 0; // ceil(n_s / chunk) <= 2 n_s / chunk for n_s > chunk
+    // ceil(n_s / chunk) <= 2 n_s / chunk for n_s > chunk, one slab for a smaller node
+    const uint32_t max_partials = max_multi ? 2 * (n / chunk) + 1 + (all_multi ? n_slots : 0) : 0;
     const size_t n_bins = static_cast<size_t>(max_multi) * 3 * num_bins;
     BVHB_TRY(slots.reserve(static_cast<size_t>(n_slots) * sizeof(Slot)));
     BVHB_TRY(items.reserve(static_cast<size_t>(n_slots) * 4));
@@ -1954,7 +1962,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     peak_bins = bin_bytes > peak_bins ? bin_bytes : peak_bins;
     if (fused_level) {
       k_level_setup<<<1, kScanBlock, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u, num_bins,
-                                                 chunk, slots.as<Slot>(), item_base.as<uint32_t>(), d_n_slots, d_n_items,
+                                                 chunk, all_multi, slots.as<Slot>(), item_base.as<uint32_t>(), d_n_slots, d_n_items,
                                                  d_multi_count, multi_list.as<uint32_t>(), d_multi_count + 1);
     } else {
       BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
@@ -1966,7 +1974,15 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
       if (rc) return rc;
     }
     if (n_bins) BVHB_TRY(hipMemsetAsync(bins.p, 0, n_bins * sizeof(Bin), stream));
-    if (39 * num_bins * 4 <= 65536) // the bins of three axes and three sets of suffix boxes fit the LDS of one block
+    if (all_multi) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_sah<true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 21 * 1024 * 4);
+      BVHB_TRY(attr);
+      k_bin_sah<true><<<max_items, kBinWaves * 64, 21 * num_bins * 4, stream>>>(
+        order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
+        tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
+        axis_best.as<AxisBest>());
+    } else if (39 * num_bins * 4 <= 65536) // the bins of three axes and three sets of suffix boxes fit the LDS of one block
       k_bin_sah<true><<<max_items, kBinWaves * 64, 39 * num_bins * 4, stream>>>(
         order[cur].as<uint32_t>(), nodes.as<BNode>(), slots.as<Slot>(), d_n_slots, item_base.as<uint32_t>(), d_n_items, chunk,
         tbox.as<float4>(), num_bins, partials.as<uint32_t>(), part_owner.as<uint32_t>(), pbins.as<uint32_t>(),
