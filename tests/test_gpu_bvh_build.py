@@ -300,3 +300,32 @@ def test_device_built_triangle_data_equals_the_reference_glm_vectors():
     fin = np.isfinite(ref).all(1)
     assert fin.mean() > 0.95
     assert (got[fin].view(np.uint32) == ref[fin].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("flavour", ["sizes_9_to_34", "shared_centres", "flat_clusters"])
+def test_small_node_path_of_the_subtree_kernel(flavour):
+    """k_subtree handles nodes of at most 16 triangles four at a time and of 17..32 two at a time, a lane per
+    triangle (bvh_build.hpp: tiny_nodes).  Scenes whose subtrees end in clusters of exactly those sizes, with many
+    triangles in one bin (equal centres: no split between them), with empty bins between occupied ones (the two
+    kinds of right boxes) and with a degenerate axis."""
+    rng = np.random.default_rng({"sizes_9_to_34": 31, "shared_centres": 32, "flat_clusters": 33}[flavour])
+    tris = []
+    for c in range(700):
+        k = 9 + c % 26  # 9..34 triangles per cluster
+        centre = rng.uniform(-50, 50, 3).astype(np.float32)
+        if flavour == "shared_centres":
+            # a few distinct centres per cluster, each shared by several triangles of different size
+            spots = centre + rng.uniform(-0.5, 0.5, (3, 3)).astype(np.float32)
+            pos = spots[rng.integers(0, 3, k)]
+        else:
+            pos = centre + rng.uniform(-0.5, 0.5, (k, 3)).astype(np.float32)
+        for p in pos:
+            half = rng.uniform(0.01, 0.2, (3, 3)).astype(np.float32)
+            half -= half.mean(axis=0, keepdims=True)  # the vertices' mean is p; the box centre is near it
+            if flavour == "flat_clusters":
+                half[:, 1] = 0.0
+                p = p.copy()
+                p[1] = centre[1]  # the whole cluster in one plane: the y axis cannot be split
+            tris.append((p + half).reshape(9))
+    host, stats = assert_same_tree(np.asarray(tris, np.float32))
+    assert stats["levels"] > 8  # the clusters are below depth 7, i.e. in k_subtree's hands
