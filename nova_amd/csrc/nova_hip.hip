@@ -635,7 +635,9 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       case 7: NOVA_LAUNCH_P(8, 5, false, false, 3);  // no forking in the drain
       case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);  // 6 waves/SIMD (spills 5-9 registers)
       case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
-      default: NOVA_LAUNCH_P(8, 5, true, false, 3); // 88-94 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9
+      default: NOVA_LAUNCH_P(16, 5, true, false, 3); // 88-96 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9.  Refill at
+                                                     // 16 idle lanes (was 8; with the near-side cull of round 2: C3 -2.8 %,
+                                                     // C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16)
     }
 #undef NOVA_LAUNCH_P
   }
