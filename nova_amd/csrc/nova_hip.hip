@@ -72,8 +72,6 @@ struct PackedScene {
   Node64* nodes = nullptr;
   Node128* wide = nullptr; // null when the input boxes are not nested (traverse.hpp)
   uint32_t n_wide = 0;
-  Node64Q* qnodes = nullptr;   // the same tree in 64-byte nodes (null: a box that cannot be put on a grid)
-  float4* leaf_box = nullptr;  // with qnodes: the box of every triangle's leaf
   // quad-per-ray layout (traverse_quad.hpp); q_wide is null when it could not be built
   NodeQ* q_wide = nullptr;
   NodeQ* q_pair = nullptr;
@@ -212,10 +210,6 @@ const Alloc* find_alloc(const void* p) {
 void free_scene(PackedScene& s) {
   (void) hipFree(s.nodes);
   (void) hipFree(s.wide);
-  (void) hipFree(s.qnodes);
-  (void) hipFree(s.leaf_box);
-  s.qnodes = nullptr;
-  s.leaf_box = nullptr;
   (void) hipFree(s.q_wide);
   (void) hipFree(s.q_pair);
   (void) hipFree(s.q_tris);
@@ -468,36 +462,6 @@ int pack_scene_device(const nova_bvh_node* bvh, const nova_triangle_data* tris, 
   return 0;
 }
 
-// Node128[] -> Node64Q[] + leaf boxes (traverse.hpp), after either packer.  A scene that cannot be quantised
-// (non-finite boxes) keeps the 128-byte nodes; so does NOVA_HIP_NO_QNODES (diagnostics).
-int quantise_scene(PackedScene& s) {
-  static const bool off = std::getenv("NOVA_HIP_NO_QNODES") != nullptr;
-  if (off || !s.wide || s.n_wide == 0 || s.n_tris == 0) return 0;
-  uint32_t* d_failed = nullptr;
-  HIP_TRY(hipMalloc(&d_failed, sizeof(uint32_t)));
-  hipError_t e = hipMemsetAsync(d_failed, 0, sizeof(uint32_t), g.stream);
-  if (e == hipSuccess) e = hipMalloc(&s.qnodes, static_cast<size_t>(s.n_wide) * sizeof(Node64Q));
-  if (e == hipSuccess) e = hipMalloc(&s.leaf_box, 2 * static_cast<size_t>(s.n_tris) * sizeof(float4));
-  // triangles that no leaf holds keep an empty box (never read: no leaf leads to them)
-  if (e == hipSuccess) e = hipMemsetAsync(s.leaf_box, 0, 2 * static_cast<size_t>(s.n_tris) * sizeof(float4), g.stream);
-  uint32_t failed = 1;
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_quantise_nodes, dim3((s.n_wide + 255) / 256), dim3(256), 0, g.stream, s.wide, s.n_wide, s.n_tris,
-                       s.qnodes, s.leaf_box, d_failed);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(&failed, d_failed, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-  (void) hipFree(d_failed);
-  if (e != hipSuccess || failed) {
-    (void) hipFree(s.qnodes);
-    (void) hipFree(s.leaf_box);
-    s.qnodes = nullptr;
-    s.leaf_box = nullptr;
-  }
-  return static_cast<int>(e);
-}
-
 int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedScene** out) {
   const Alloc* ab = find_alloc(bvh);
   const Alloc* at = find_alloc(tris);
@@ -518,11 +482,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   int rc = 1;
   if (!host_pack_only() && !want_quad) rc = pack_scene_device(bvh, tris, ab, at, s);
   if (rc == 1) rc = pack_scene_host(bvh, tris, ab, at, want_quad, s);
-  if (rc == 0) rc = quantise_scene(s);
-  if (rc) {
-    free_scene(s);
-    return rc;
-  }
+  if (rc) return rc;
   g.scenes.push_back(s);
   *out = &g.scenes.back();
   return 0;
@@ -660,8 +620,6 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
     g.spill_words = words;
   }
   A.wide = s.wide;
-  A.qnodes = s.qnodes;
-  A.leaf_box = s.leaf_box;
   A.spill = g.d_spill;
   A.rays_per_wave = (g.opt_tune & 0xFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFF) : 64u;
   const dim3 grid(blocks), block(256);
@@ -677,16 +635,9 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       case 7: NOVA_LAUNCH_P(8, 5, false, false, 3);  // no forking in the drain
       case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);  // 6 waves/SIMD (spills 5-9 registers)
       case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
-      case 23: NOVA_LAUNCH_P(16, 5, true, false, 3); // the 128-byte nodes (A/B against the default)
-      default:
-        // 88-96 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9.  Refill at 16 idle lanes (was 8; with the near-side cull
-        // of round 2: C3 -2.8 %, C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16).  64-byte nodes where the scene has them.
-        if (s.qnodes != nullptr) {
-          if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
-          else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
-          return static_cast<int>(hipGetLastError());
-        }
-        NOVA_LAUNCH_P(16, 5, true, false, 3);
+      default: NOVA_LAUNCH_P(16, 5, true, false, 3); // 88-96 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9.  Refill at
+                                                     // 16 idle lanes (was 8; with the near-side cull of round 2: C3 -2.8 %,
+                                                     // C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16)
     }
 #undef NOVA_LAUNCH_P
   }

@@ -59,32 +59,6 @@ struct __attribute__((aligned(128))) Node128 {
   float e[4];      // cull slack of the child's subtree (world units, slab rounding included)
 };
 
-// The four-wide node in 64 bytes (production): the same tree as Node128[], node for node, with the child boxes
-// quantised to 8 bits per coordinate on a grid of the node's own (origin = lower corner of the union of its
-// children, one scale per axis) and the slacks rounded up to bf16: four 16-byte loads per node step instead of
-// eight, and half the lines per node (scripts/ubench_node64.hip: 2-2.5x the node records per second).
-// A coordinate decodes as fma(q, scale, origin) — ONE rounding, monotone in q — and k_quantise_nodes picks q so
-// that the decoded box CONTAINS the child's box as float numbers; the slab bounds are then the reference's
-// fma(c, inv, nio) on those coordinates, monotone in c, so "child box pierced" still implies "decoded box
-// pierced": inner boxes only ever had to be supersets (see Node128).  What must be exact is the LEAF's own box —
-// the reference reaches a triangle if and only if the line pierces it — so the leaf step tests that box, kept per
-// triangle in TraverseArgs::leaf_box, before any triangle of the leaf (a decoded box that is pierced where
-// the leaf's is not costs two loads, never a wrong hit).
-//   w0: origin.xyz, scales = fx | fy << 11 | fz << 22, each f a 10-bit float (8 exponent bits, 2 mantissa bits;
-//       bits 10 and 21 are zero), and scale_x = bits(scales << 21), scale_y = bits(scales << 10),
-//       scale_z = bits(scales >> 1): the field lands on the exponent and the top of the mantissa, whatever lies
-//       below it — any positive number does as a scale as long as the packer used the same one
-//   w1: ref[4] as in Node128
-//   w2: lower corners: byte k of .x/.y/.z = child k's q on that axis; .w = e0 | e1 << 16 (bf16, rounded up)
-//   w3: upper corners likewise; .w = e2 | e3 << 16.  An unused slot has e = NaN (never hit).
-struct __attribute__((aligned(64))) Node64Q {
-  float origin[3];
-  uint32_t scales;
-  uint32_t ref[4];
-  uint32_t qlo[3], e01;
-  uint32_t qhi[3], e23;
-};
-
 struct LeafRec {
   uint32_t first, count;
   float top[3], bot[3];
@@ -119,106 +93,7 @@ struct TraverseArgs {
   uint32_t flags;                    // bits 0-1 = RayQueue mode, bit 2 = ray kinds interleaved
   const uint32_t* perm;              // k_traverse_p: queue position w takes ray perm[w] (rays binned by origin cell and
                                      // direction octant, k_ray_keys), or null
-  const Node64Q* qnodes;             // k_traverse_p<.., QN = true>: the four-wide tree in 64-byte nodes
-  const float4* leaf_box;            // with qnodes: [2 i] = lower, [2 i + 1] = upper corner of the box of triangle i's leaf
 };
-
-// ---- Node128[] -> Node64Q[] + leaf boxes (one thread per node; run once per scene after either packer) --------
-NV_DEV float q_decode(uint32_t q, float scale, float origin) { return fma_(static_cast<float>(q), scale, origin); }
-NV_DEV uint32_t bf16_up(float e) { // smallest bf16 >= e for e >= 0; NaN stays NaN
-  const uint32_t b = __float_as_uint(e);
-  if (!(e == e)) return 0x7FC0u;
-  return min((b + 0xFFFFu) >> 16, 0x7F80u);
-}
-__global__ __launch_bounds__(256) void k_quantise_nodes(const Node128* __restrict__ wide, uint32_t n_wide, uint32_t n_tris,
-                                                        Node64Q* __restrict__ out, float4* __restrict__ leaf_box,
-                                                        uint32_t* __restrict__ failed) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_wide) return;
-  const Node128 nd = wide[i];
-  const float inf = __builtin_huge_valf();
-  float lo[3][4], hi[3][4];
-  for (int a = 0; a < 3; a++) {
-    const float l[4] = { nd.lo[a].x, nd.lo[a].y, nd.lo[a].z, nd.lo[a].w }, h[4] = { nd.hi[a].x, nd.hi[a].y, nd.hi[a].z, nd.hi[a].w };
-    for (int k = 0; k < 4; k++) { lo[a][k] = l[k]; hi[a][k] = h[k]; }
-  }
-  bool bad = false;
-  float org[3], ext[3];
-  for (int a = 0; a < 3; a++) {
-    float mn = inf, mx = -inf;
-    for (int k = 0; k < 4; k++) {
-      if (nd.ref[k] == kEmptyRef) continue;
-      // a box that is not a pair of finite, ordered numbers cannot be put on a grid
-      if (!(__builtin_fabsf(lo[a][k]) < inf) || !(__builtin_fabsf(hi[a][k]) < inf) || !(lo[a][k] <= hi[a][k])) bad = true;
-      mn = min_(mn, lo[a][k]);
-      mx = max_(mx, hi[a][k]);
-    }
-    org[a] = mn;
-    ext[a] = mx - mn;
-    if (!(ext[a] >= 0.0f) || !(ext[a] < inf)) bad = true;
-  }
-  Node64Q q;
-  uint32_t ex[3] = { 4u, 4u, 4u };
-  if (!bad) {
-    // the 10-bit float just below ext / 255 (what the grid needs); the loop below moves up from there
-    for (int a = 0; a < 3; a++) ex[a] = min(max((__float_as_uint(ext[a] * (1.0f / 255.0f)) >> 21) & 0x3FFu, 4u), 0x3FBu);
-    bool done = false;
-    for (int attempt = 0; attempt < 12 && !done; attempt++) {
-      const uint32_t word = ex[0] | (ex[1] << 11) | (ex[2] << 22);
-      const float sc[3] = { __uint_as_float(word << 21), __uint_as_float(word << 10), __uint_as_float(word >> 1) };
-      done = true;
-      for (int a = 0; a < 3; a++) {
-        uint32_t wl = 0, wh = 0;
-        bool fits = true;
-        for (int k = 0; k < 4; k++) {
-          if (nd.ref[k] == kEmptyRef) continue;
-          const float fl = __builtin_floorf((lo[a][k] - org[a]) / sc[a]);
-          uint32_t ql = fl > 0.0f ? static_cast<uint32_t>(min_(fl, 255.0f)) : 0u;
-          while (ql > 0u && q_decode(ql, sc[a], org[a]) > lo[a][k]) ql--;
-          const float fh = __builtin_ceilf((hi[a][k] - org[a]) / sc[a]);
-          uint32_t qh = fh > 0.0f ? static_cast<uint32_t>(min_(fh, 255.0f)) : 0u;
-          while (qh < 255u && q_decode(qh, sc[a], org[a]) < hi[a][k]) qh++;
-          if (q_decode(ql, sc[a], org[a]) > lo[a][k] || q_decode(qh, sc[a], org[a]) < hi[a][k]) fits = false;
-          wl |= ql << (8 * k);
-          wh |= qh << (8 * k);
-        }
-        q.qlo[a] = wl;
-        q.qhi[a] = wh;
-        if (!fits) {
-          done = false;
-          if (ex[a] < 0x3FBu) ex[a]++;
-          else bad = true;
-        }
-      }
-      q.scales = word;
-      if (bad) break;
-    }
-    if (!done) bad = true;
-  }
-  if (bad) {
-    atomicOr(failed, 1u);
-    return;
-  }
-  for (int a = 0; a < 3; a++) q.origin[a] = org[a];
-  const float es[4] = { nd.e[0], nd.e[1], nd.e[2], nd.e[3] };
-  uint32_t eb[4];
-  for (int k = 0; k < 4; k++) {
-    q.ref[k] = nd.ref[k];
-    eb[k] = nd.ref[k] == kEmptyRef ? 0x7FC0u : (es[k] >= 0.0f ? bf16_up(es[k]) : 0x7F80u); // a NaN or negative slack: never cull
-  }
-  q.e01 = eb[0] | (eb[1] << 16);
-  q.e23 = eb[2] | (eb[3] << 16);
-  out[i] = q;
-  for (int k = 0; k < 4; k++) {
-    const uint32_t ref = nd.ref[k];
-    if (ref == kEmptyRef || !(ref & kLeafBit)) continue;
-    const uint32_t first = ref & 0x00FFFFFFu, count = ((ref >> 24) & 0x7Fu) + 1u;
-    for (uint32_t t = first; t < first + count && t < n_tris; t++) {
-      leaf_box[2 * static_cast<size_t>(t)] = make_float4(lo[0][k], lo[1][k], lo[2][k], 0.0f);
-      leaf_box[2 * static_cast<size_t>(t) + 1] = make_float4(hi[0][k], hi[1][k], hi[2][k], 0.0f);
-    }
-  }
-}
 
 // ---- ray binning for incoherent batches -------------------------------------------------------------
 // A batch of random rays over a scene that does not fit the caches (BASELINE config 4: 0.6 GB of nodes and
@@ -781,7 +656,7 @@ NV_DEV unsigned long long hit_key(const HitState& h) {
                    : ~0ull;
 }
 
-template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK, bool LAZY = false, int TPS = kTrisPerStep, bool QN = false>
+template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK, bool LAZY = false, int TPS = kTrisPerStep>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   __shared__ uint32_t lds_stack[4][SLDS][64];
   // FORK: records of the rays that were split among several lanes of the wave (index = the lane
@@ -956,47 +831,21 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
           fin = true;
         }
       } else if (cur < kDone) {
+        const Node128* nd = A.wide + cur;
         if (FORK && forked) { // another member of the family may have found something closer
           const float ft = __uint_as_float(static_cast<uint32_t>(rec_key[fam] >> 32));
           if (ft < h.t) far_limit = min_(far_limit, fma_(ft, kCullRel, ft));
         }
+        const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
+        const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];
+        const uint4 rf = *reinterpret_cast<const uint4*>(nd->ref);
+        const float4 es = *reinterpret_cast<const float4*>(nd->e);
+        if (COUNT) n_nodes += 2;
         float key[4];
-        uint32_t ref[4];
-        float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4], ess[4];
-        if (QN) {
-          const uint4* nd = reinterpret_cast<const uint4*>(A.qnodes + cur);
-          const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
-          if (COUNT) n_nodes += 1;
-          const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-          const float sx = __uint_as_float(w0.w << 21), sy = __uint_as_float(w0.w << 10), sz = __uint_as_float(w0.w >> 1);
-          ref[0] = w1.x; ref[1] = w1.y; ref[2] = w1.z; ref[3] = w1.w;
-          ess[0] = __uint_as_float(w2.w << 16); ess[1] = __uint_as_float(w2.w & 0xFFFF0000u);
-          ess[2] = __uint_as_float(w3.w << 16); ess[3] = __uint_as_float(w3.w & 0xFFFF0000u);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            lxs[k] = fma_(static_cast<float>((w2.x >> (8 * k)) & 0xFFu), sx, ox);
-            lys[k] = fma_(static_cast<float>((w2.y >> (8 * k)) & 0xFFu), sy, oy);
-            lzs[k] = fma_(static_cast<float>((w2.z >> (8 * k)) & 0xFFu), sz, oz);
-            hxs[k] = fma_(static_cast<float>((w3.x >> (8 * k)) & 0xFFu), sx, ox);
-            hys[k] = fma_(static_cast<float>((w3.y >> (8 * k)) & 0xFFu), sy, oy);
-            hzs[k] = fma_(static_cast<float>((w3.z >> (8 * k)) & 0xFFu), sz, oz);
-          }
-        } else {
-          const Node128* nd = A.wide + cur;
-          const float4 lx = nd->lo[0], ly = nd->lo[1], lz = nd->lo[2];
-          const float4 hx = nd->hi[0], hy = nd->hi[1], hz = nd->hi[2];
-          const uint4 rf = *reinterpret_cast<const uint4*>(nd->ref);
-          const float4 es = *reinterpret_cast<const float4*>(nd->e);
-          if (COUNT) n_nodes += 2;
-          ref[0] = rf.x; ref[1] = rf.y; ref[2] = rf.z; ref[3] = rf.w;
-          lxs[0] = lx.x; lxs[1] = lx.y; lxs[2] = lx.z; lxs[3] = lx.w;
-          lys[0] = ly.x; lys[1] = ly.y; lys[2] = ly.z; lys[3] = ly.w;
-          lzs[0] = lz.x; lzs[1] = lz.y; lzs[2] = lz.z; lzs[3] = lz.w;
-          hxs[0] = hx.x; hxs[1] = hx.y; hxs[2] = hx.z; hxs[3] = hx.w;
-          hys[0] = hy.x; hys[1] = hy.y; hys[2] = hy.z; hys[3] = hy.w;
-          hzs[0] = hz.x; hzs[1] = hz.y; hzs[2] = hz.z; hzs[3] = hz.w;
-          ess[0] = es.x; ess[1] = es.y; ess[2] = es.z; ess[3] = es.w;
-        }
+        uint32_t ref[4] = { rf.x, rf.y, rf.z, rf.w };
+        const float lxs[4] = { lx.x, lx.y, lx.z, lx.w }, lys[4] = { ly.x, ly.y, ly.z, ly.w }, lzs[4] = { lz.x, lz.y, lz.z, lz.w };
+        const float hxs[4] = { hx.x, hx.y, hx.z, hx.w }, hys[4] = { hy.x, hy.y, hy.z, hy.w }, hzs[4] = { hz.x, hz.y, hz.z, hz.w };
+        const float ess[4] = { es.x, es.y, es.z, es.w };
         uint32_t n_hit = 0;
         // Near side of the cull: "the box widened by the child's slack e lies behind the origin".  The ray leaves
         // that box at min over the axes of far_a + e |1/d_a| — its slab test — which is far tighter than
@@ -1042,7 +891,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
         bool finished = false;
-        static_assert(!(LAZY && QN), "the two-round leaf step does not test the leaf's own box");
         if (LAZY) {
           // Two rounds of loads: the z rows first (they give t), then the x and y rows of the
           // triangles whose t can still win.  A vector load costs ~17 cycles of the CU's memory
@@ -1085,17 +933,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
           // and without L1 allocation each row is its own L2 request)
           tm[k][0] = m[0]; tm[k][1] = m[1]; tm[k][2] = m[2];
         }
-        bool pierced = true;
-#ifndef NOVA_QN_NO_LEAFBOX // (timing experiments only: wrong hits without it)
-        if (QN) { // the leaf's own box, as the reference tests it (a box-pair lane has tested it already)
-          const float4 bl = A.leaf_box[2 * static_cast<size_t>(first)], bh = A.leaf_box[2 * static_cast<size_t>(first) + 1];
-          float tn, tf;
-          pierced = slab(r, bh, bl, tn, tf) || pair;
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < TPS; k++) {
-          if (!finished && pierced && count > static_cast<uint32_t>(k)) {
+          if (!finished && count > static_cast<uint32_t>(k)) {
             if (COUNT) n_tris++;
             if (woop(r, h, static_cast<int>(first + k), tm[k][0], tm[k][1], tm[k][2])) {
               finished = anyhit;

@@ -18,11 +18,14 @@ ap.add_argument("--batches", type=int, default=8)
 ap.add_argument("--prof", action="store_true")
 ap.add_argument("--triangles", type=int, default=10_000_000)
 ap.add_argument("--rays", type=int, default=1 << 24)
+ap.add_argument("--kernel", type=int, default=0, help="NOVA_HIP_OPT_TRAVERSE_KERNEL (A/B)")
 ap.add_argument("--sort", type=int, default=0, help="NOVA_HIP_OPT_SORT_RAYS: 0 auto, 1 never, 2 always")
 args = ap.parse_args()
 
 capi.init(0)
 capi.set_option(capi.OPT_SORT_RAYS, args.sort)
+if args.kernel:
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, args.kernel)
 n_tri, n = args.triangles, args.rays
 vb = capi.Buffer(S.soup(n_tri, seed=4))
 bvh, tris, order, n_nodes, stats = capi.build_bvh_device(vb, n_tri)
