@@ -25,12 +25,19 @@ struct Packer {
   std::vector<uint32_t> child_node[2];
   uint32_t max_depth = 0;
   bool bad = false;
-  bool nested = true; // every child box lies inside its parent's box
+  bool nested = true; // every child box lies inside its parent's box, and every box has bottom <= top
 
   static bool inside(const nova_bvh_node& c, const nova_bvh_node& p) {
     return c.top_offset_left.x <= p.top_offset_left.x && c.top_offset_left.y <= p.top_offset_left.y &&
            c.top_offset_left.z <= p.top_offset_left.z && c.bottom_num_right.x >= p.bottom_num_right.x &&
            c.bottom_num_right.y >= p.bottom_num_right.y && c.bottom_num_right.z >= p.bottom_num_right.z;
+  }
+
+  // bottom <= top on every axis (false for NaN): the four-wide node step reads "the plane the ray meets first"
+  // by the sign of 1/d instead of taking min / max of both, which is the same value only for such a box
+  static bool ordered(const nova_bvh_node& n) {
+    return n.bottom_num_right.x <= n.top_offset_left.x && n.bottom_num_right.y <= n.top_offset_left.y &&
+           n.bottom_num_right.z <= n.top_offset_left.z;
   }
 
   static bool is_leaf(const nova_bvh_node& n) { return !(n.bottom_num_right.w >= 0.0f); }
@@ -79,6 +86,7 @@ struct Packer {
     *leaf = -1;
     if (bad) return kLeafBit;
     const nova_bvh_node& n = in[i];
+    if (!ordered(n)) nested = false;
     if (is_leaf(n)) {
       const float foff = n.top_offset_left.w, fcnt = -n.bottom_num_right.w;
       if (!(foff >= 0.0f) || !(fcnt >= 1.0f) || foff >= 16777216.0f || fcnt > 16777216.0f) { bad = true; return kLeafBit; }

@@ -474,6 +474,8 @@ __global__ void k_flat_check(const nova_bvh_node* __restrict__ in, const FlatInf
   b.slot = 0;
   b.size = f.end - i;
   uint32_t flag = 0;
+  // bottom <= top on every axis (Packer::ordered)
+  if (!(b.bot[0] <= b.top[0]) || !(b.bot[1] <= b.top[1]) || !(b.bot[2] <= b.top[2])) flag |= kFlagNotNested;
   if (f.end == 0 || f.end > n_nodes) {
     flag |= kFlagBad;
   } else if (f.right) {

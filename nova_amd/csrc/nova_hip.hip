@@ -703,8 +703,9 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // 16-19 = k_traverse_q (four lanes per ray; measured slower) for every launch
   const bool quad = cull && s.q_wide != nullptr && g.opt_kernel >= 16 && g.opt_kernel <= 19;
   const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;  // 20, 21: k_traverse_p with two-round leaf loads
-  const bool wide = cull && !quad && ((base && !coherent) || g.opt_kernel == 6 || g.opt_kernel == 7 || g.opt_kernel == 14);
-  const bool packet = cull && !quad && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  // 22 = the per-lane kernel for camera rays too (A/B)
+  const bool wide = cull && !quad && ((base && !coherent) || g.opt_kernel == 6 || g.opt_kernel == 7 || g.opt_kernel == 14 || g.opt_kernel == 22);
+  const bool packet = cull && !quad && g.opt_kernel != 22 && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
   // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
   // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on
   // the 1080p frame: 3.79 -> 3.30 ms of traversal (each XCD's L2 then serves one part of the frame).

@@ -312,6 +312,30 @@ def test_tree_with_boxes_that_are_not_nested_is_walked_like_the_reference(soup50
         assert (got == ref).all()
 
 
+def test_tree_with_a_box_whose_corners_are_swapped_is_walked_like_the_reference(soup50k):
+    """intersects_aabb takes min / max of the two bounds of an axis (kernels/intersection.hpp:40-52), so a box
+    whose `top` is below its `bottom` on an axis is the same box to the reference.  The four-wide node step reads
+    the nearer plane by the sign of 1/d instead, which is the same value only when bottom <= top: such a tree
+    must not be collapsed (Packer::ordered) and still gives the reference's hits."""
+    O = oracle()
+    bvh = soup50k.bvh.copy()
+    rng = np.random.default_rng(5)
+    pick = rng.choice(np.arange(1, bvh.shape[0]), 300, replace=False)
+    axis = rng.integers(0, 3, pick.size)
+    t = bvh["top_offset_left"][pick, axis].copy()
+    bvh["top_offset_left"][pick, axis] = bvh["bottom_num_right"][pick, axis]
+    bvh["bottom_num_right"][pick, axis] = t
+    import dataclasses
+    sc = dataclasses.replace(soup50k, bvh=bvh)
+    pt, df = random_rays(200000, seed=9)
+    ref = O.trace_rays(sc, pt, df).view(np.uint32)
+    base = O.trace_rays(soup50k, pt, df).view(np.uint32)
+    assert (ref == base).all()  # the same boxes to the reference
+    for kernel in (0, 6):
+        got = _trace(sc.triangles, bvh, pt, df, kernel=kernel)
+        assert (got == ref).all()
+
+
 @pytest.mark.parametrize("flags", [0x100, 0x1, 0x2, 0x3, 0x5, 0xD])
 def test_ray_queue_order_does_not_change_results(flags, knot_small):
     """The ray queue may hand rays to waves in any order (sub-queue mapping per XCD, the three rays of a
