@@ -417,6 +417,33 @@ struct HybridStack {
     --sp;
     return sp < SLDS ? lds[sp][lane] : spill[static_cast<size_t>(sp - SLDS) * stride];
   }
+  // The two below are for an LDS part of SLDS + 1 rows (k_traverse_p): row SLDS takes the writes that belong in
+  // the spill area, so that the common case is straight-line LDS code.  (pop() above compiles to ONE flat load
+  // from a selected address — LDS through the vector-memory path, in the dependent chain of every step.)
+  NV_DEV uint32_t pop_lds() {
+    --sp;
+    uint32_t v = lds[min(sp, static_cast<uint32_t>(SLDS))][lane];
+    asm volatile("" : "+v"(v)); // keeps this a ds_read: without it the two loads are merged into one flat load again
+    if (sp >= SLDS) v = spill[static_cast<size_t>(sp - SLDS) * stride];
+    return v;
+  }
+  // push c, b, a (in this order) where n > 3, n > 2, n > 1: entries above the top of the stack are free, so the
+  // three LDS writes need no predicate, only the stack pointer does
+  NV_DEV void push_upto3(uint32_t n, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t sp0 = sp;
+    lds[min(sp, static_cast<uint32_t>(SLDS))][lane] = c;
+    sp += n > 3u ? 1u : 0u;
+    lds[min(sp, static_cast<uint32_t>(SLDS))][lane] = b;
+    sp += n > 2u ? 1u : 0u;
+    lds[min(sp, static_cast<uint32_t>(SLDS))][lane] = a;
+    sp += n > 1u ? 1u : 0u;
+    if (sp > SLDS) { // some of them belong in the spill area (rare)
+      uint32_t q = sp0;
+      if (n > 3u) { if (q >= SLDS) spill[static_cast<size_t>(q - SLDS) * stride] = c; q++; }
+      if (n > 2u) { if (q >= SLDS) spill[static_cast<size_t>(q - SLDS) * stride] = b; q++; }
+      if (n > 1u) { if (q >= SLDS) spill[static_cast<size_t>(q - SLDS) * stride] = a; q++; }
+    }
+  }
 };
 
 NV_DEV void ray_setup(float4 o4, float4 d4, RayState& r) {
@@ -661,7 +688,7 @@ NV_DEV unsigned long long hit_key(const HitState& h) {
 
 template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK, bool LAZY = false, int TPS = kTrisPerStep>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
-  __shared__ uint32_t lds_stack[4][SLDS][64];
+  __shared__ uint32_t lds_stack[4][SLDS + 1][64]; // row SLDS: see HybridStack::push_upto3
   // FORK: records of the rays that were split among several lanes of the wave (index = the lane
   // that loaded the ray): best (t, index) key, its t bits / u / v, members still running
   __shared__ unsigned long long rec_key_[4][64];
@@ -895,13 +922,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         cswap(key[0], ref[0], key[2], ref[2]);
         cswap(key[1], ref[1], key[3], ref[3]);
         cswap(key[1], ref[1], key[2], ref[2]);
-        if (n_hit > 3) st.push(ref[3]);
-        if (n_hit > 2) st.push(ref[2]);
-        if (n_hit > 1) st.push(ref[1]);
+        st.push_upto3(n_hit, ref[1], ref[2], ref[3]);
         if (n_hit > 0) {
           cur = ref[0];
         } else if (st.sp != 0) {
-          cur = st.pop();
+          cur = st.pop_lds();
         } else {
           fin = true;
         }
@@ -949,9 +974,17 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
           }
         } else {
         float4 tm[TPS][3];
+        // byte offsets (n_tris <= 2^24, so they fit 32 bits and the one product is a 24-bit multiply)
+        const uint32_t off0 = __umul24(first, 48u), last_off = (A.n_tris - 1u) * 48u;
+        uint32_t off[TPS];
 #pragma unroll
         for (int k = 0; k < TPS; k++) {
-          const float4* m = A.tris + 3 * static_cast<size_t>(min(first + k, A.n_tris - 1u));
+          off[k] = min(off0 + 48u * k, last_off);
+          asm volatile("" : "+v"(off[k])); // every offset before the first load: a wait for an older load that the
+        }                                  // scheduler puts between the loads would serialise them
+#pragma unroll
+        for (int k = 0; k < TPS; k++) {
+          const float4* m = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A.tris) + off[k]);
           // (non-temporal loads here were 1.45x slower: the three rows of a triangle share a line,
           // and without L1 allocation each row is its own L2 request)
           tm[k][0] = m[0]; tm[k][1] = m[1]; tm[k][2] = m[2];
@@ -971,7 +1004,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         if (!finished && count > static_cast<uint32_t>(TPS)) {
           cur = kLeafBit | ((count - TPS - 1u) << 24) | (first + TPS);
         } else if (!finished && st.sp != 0) {
-          cur = st.pop();
+          cur = st.pop_lds();
         } else {
           fin = true;
         }
