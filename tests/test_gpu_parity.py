@@ -336,6 +336,31 @@ def test_tree_with_a_box_whose_corners_are_swapped_is_walked_like_the_reference(
         assert (got == ref).all()
 
 
+def test_overlapping_boxes_fill_the_stack_beyond_its_lds_part():
+    """Large triangles all over the scene box: nearly every child box of every node is pierced, so a lane holds three
+    more entries per level and runs past the 16 LDS rows of its stack into the spill area (HybridStack::push_upto3 /
+    pop_lds: the row that takes those writes, the copy in global memory).  Checked once with a printf in that branch:
+    14 419 pushes into the spill area on this batch, stack pointers up to 20."""
+    sc = S.build_scene(S.soup(30000, seed=7, edge=0.9))
+    pt, df = random_rays(60000, seed=12)
+    walk = _trace(sc.triangles, sc.bvh, pt, df, traversal=1)
+    got = _trace(sc.triangles, sc.bvh, pt, df)
+    ref = oracle().trace_rays(sc, pt, df).view(np.uint32)
+    anyhit = (df[:, 3].view(np.uint32) & 1) == 1
+    assert (walk[~anyhit] == ref[~anyhit]).all()
+    assert (got[~anyhit] == ref[~anyhit]).all()
+    assert ((got[anyhit, 3].view(np.int32) >= 0) == (ref[anyhit, 3].view(np.int32) >= 0)).all()
+    # the stack really is that deep: work counters of a culled closest-hit batch on this scene
+    capi.set_option(capi.OPT_COUNT_WORK, 1)
+    try:
+        capi.reset_counters()
+        _trace(sc.triangles, sc.bvh, pt, df)
+        k = capi.counters()
+    finally:
+        capi.set_option(capi.OPT_COUNT_WORK, 0)
+    assert k["node_visits"] / 2 / len(pt) > 60  # four-wide node steps per ray: far more than a surface mesh needs
+
+
 @pytest.mark.parametrize("flags", [0x100, 0x1, 0x2, 0x3, 0x5, 0xD])
 def test_ray_queue_order_does_not_change_results(flags, knot_small):
     """The ray queue may hand rays to waves in any order (sub-queue mapping per XCD, the three rays of a
