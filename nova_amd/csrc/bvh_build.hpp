@@ -162,7 +162,11 @@ __global__ void k_tri_bounds(const float* __restrict__ verts, uint32_t n, float4
   }
 }
 
-__global__ void k_root(const uint32_t* __restrict__ root, uint32_t n, BNode* __restrict__ nodes) {
+// `lv` (where given): lv[d] .. lv[d + 1] are the nodes of level d — the level loop's ls / le kept on the device, so
+// that the top levels can be enqueued without the host learning how many nodes each one has (build(): blind levels)
+__global__ void k_root(const uint32_t* __restrict__ root, uint32_t n, BNode* __restrict__ nodes, uint32_t* __restrict__ lv) {
+  lv[0] = 0;
+  lv[1] = 1;
   BNode nd;
   for (int a = 0; a < 3; a++) {
     nd.top[a] = dec_max(root[a]);
@@ -338,7 +342,12 @@ __global__ void __launch_bounds__(kScanBlock) k_level_setup(BNode* __restrict__ 
                                                             uint32_t num_bins, uint32_t chunk, bool all_multi, Slot* __restrict__ slots,
                                                             uint32_t* __restrict__ item_base, uint32_t* __restrict__ n_slots_out,
                                                             uint32_t* __restrict__ n_items_out, uint32_t* __restrict__ multi_count,
-                                                            uint32_t* __restrict__ multi_list, uint32_t* __restrict__ multi_items) {
+                                                            uint32_t* __restrict__ multi_list, uint32_t* __restrict__ multi_items,
+                                                            const uint32_t* __restrict__ lv) {
+  if (lv) { // a blind level: the host passed bounds
+    ls = lv[0];
+    m = lv[1] - lv[0];
+  }
   if (threadIdx.x == 0) {
     *multi_count = 0;
     *multi_items = 0;
@@ -816,7 +825,7 @@ __global__ void k_choose(const Slot* __restrict__ slots, const uint32_t* __restr
 __global__ void __launch_bounds__(kScanBlock) k_choose_scan(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
                                                             const BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
                                                             Choice* __restrict__ choice, uint32_t* __restrict__ split_rank,
-                                                            uint32_t* __restrict__ total) {
+                                                            uint32_t* __restrict__ total, uint32_t* __restrict__ lv) {
   const uint32_t n_slots = *n_slots_ptr;
   uint32_t carry = 0;
   for (uint32_t start = 0; start < n_slots; start += kScanBlock) {
@@ -849,16 +858,20 @@ __global__ void __launch_bounds__(kScanBlock) k_choose_scan(const Slot* __restri
     if (s < n_slots) split_rank[s] = ex;
     carry += sum;
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0) {
+    *total = carry;
+    if (lv) lv[2] = lv[1] + 2u * carry; // where the next level ends
+  }
 }
 
 // bvh.cpp:107-118: the two child records
 __global__ void k_make_children(const Slot* __restrict__ slots, const uint32_t* __restrict__ n_slots_ptr,
                                 BNode* __restrict__ nodes, const AxisBest* __restrict__ axis_best,
                                 Choice* __restrict__ choice, const uint32_t* __restrict__ split_rank,
-                                uint32_t level_end) {
+                                uint32_t level_end, const uint32_t* __restrict__ lv) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= *n_slots_ptr) return;
+  if (lv) level_end = lv[1];
   Choice& c = choice[s];
   if (c.axis < 0) return;
   BNode& nd = nodes[slots[s].node];
@@ -899,9 +912,10 @@ __device__ __forceinline__ uint32_t goes_left_at(uint32_t k, const uint32_t* __r
 }
 __global__ void k_goes_left(const uint32_t* __restrict__ node_of, uint32_t n, const BNode* __restrict__ nodes,
                             uint32_t ls, const Choice* __restrict__ choice, const uint32_t* __restrict__ pbins,
-                            uint32_t* __restrict__ goes_left) {
+                            uint32_t* __restrict__ goes_left, const uint32_t* __restrict__ lv) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
+  if (lv) ls = lv[0];
   goes_left[k] = goes_left_at(k, node_of, nodes, ls, choice, pbins);
 }
 // k_goes_left folded into the first and the last pass of the three-pass scan (k_scan_reduce, k_scan_apply): the flags
@@ -911,7 +925,9 @@ __global__ void __launch_bounds__(kScanBlock) k_gl_scan_reduce(const uint32_t* _
                                                                const Choice* __restrict__ choice,
                                                                const uint32_t* __restrict__ pbins,
                                                                uint32_t* __restrict__ goes_left,
-                                                               uint32_t* __restrict__ block_sums) {
+                                                               uint32_t* __restrict__ block_sums,
+                                                               const uint32_t* __restrict__ lv) {
+  if (lv) ls = lv[0];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   uint32_t s = 0;
   for (uint32_t j = 0; j < kScanItems; j++)
@@ -929,9 +945,11 @@ __global__ void __launch_bounds__(kScanBlock) k_gl_scan_reduce(const uint32_t* _
 __global__ void k_scatter(const uint32_t* __restrict__ order, const uint32_t* __restrict__ node_of, uint32_t n,
                           const BNode* __restrict__ nodes, uint32_t ls, const Choice* __restrict__ choice,
                           const uint32_t* __restrict__ goes_left, const uint32_t* __restrict__ left_before,
-                          uint32_t* __restrict__ order_out, uint32_t* __restrict__ node_of_out) {
+                          uint32_t* __restrict__ order_out, uint32_t* __restrict__ node_of_out,
+                          const uint32_t* __restrict__ lv) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
+  if (lv) ls = lv[0];
   const uint32_t nd = node_of[k];
   uint32_t pos = k, owner = nd;
   if (nd >= ls) {
@@ -965,6 +983,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ order, const uint32_t* __
 // them to their final ids: "stage" l of the final array holds the nodes of local level l of every root, so that
 // the stage list (top levels, then local levels 1, 2, ...) is still a layering with parents before children,
 // which is all the later passes (sizes, flattening, bvh_pack_device.hpp) need of "levels".
+constexpr uint32_t kMaxBlindLevels = 16;
 constexpr uint32_t kSmallTris = 2048;
 constexpr uint32_t kSmallMinDepth = 7;
 constexpr uint32_t kSmallBins = 128;   // bins at kSmallMinDepth: 1024 / 8
@@ -1816,7 +1835,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     BVHB_TRY(node_of[i].reserve(static_cast<size_t>(n) * 4));
   }
   BVHB_TRY(nodes.reserve(cap * sizeof(BNode)));
-  BVHB_TRY(misc.reserve(64));
+  BVHB_TRY(misc.reserve(64 + 4 * kMaxBlindLevels + 16));
   BVHB_TRY(gl.reserve(static_cast<size_t>(n) * 4));
   BVHB_TRY(gls.reserve(static_cast<size_t>(n) * 4));
   BVHB_TRY(pbins.reserve(static_cast<size_t>(n) * 4));
@@ -1825,8 +1844,9 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   uint32_t* d_multi_count = misc.as<uint32_t>() + 9; // + 10: slabs handed out
   uint32_t* d_n_slots = misc.as<uint32_t>() + 11;
   uint32_t* d_n_items = misc.as<uint32_t>() + 12;
+  uint32_t* d_lv = misc.as<uint32_t>() + 16; // kMaxBlindLevels + 3 words: the level list of the blind levels
   uint32_t* h_total = nullptr;
-  BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64));
+  BVHB_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_total), 64 + 4 * kMaxBlindLevels + 16));
   struct Pinned {
     uint32_t* p;
     ~Pinned() { (void) hipHostFree(p); }
@@ -1908,15 +1928,46 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
   BVHB_TRY(hipMemsetAsync(d_root, 0, 64, stream));
   k_tri_bounds<<<grid(n) < 1024u ? grid(n) : 1024u, kB, 0, stream>>>(d_verts, n, tbox.as<float4>(), d_root, order[0].as<uint32_t>(),
                                           node_of[0].as<uint32_t>());
-  k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>());
+  k_root<<<1, 1, 0, stream>>>(d_root, n, nodes.as<BNode>(), d_lv);
+
+  // Blind levels.  The host needs a level's node count only to size grids and to stop; waiting for it costs a round
+  // trip per level (~25 us of a ~150 us level).  The first levels of a big build are sure to split — a node leaves
+  // the loop at kSmallTris triangles, i.e. around depth log2(n / kSmallTris) — and hold at most 2^depth nodes, so
+  // they are enqueued with that bound for the grids while ls / le stay on the device (d_lv); the host reads the
+  // whole list once, when it takes over.  A tree that ended earlier just ran a few empty levels.
+  uint32_t blind_levels = 0;
+  if (small_tris) {
+    while ((static_cast<uint64_t>(small_tris) << (blind_levels + 1)) <= n && (2u << blind_levels) <= kFusedLevelNodes &&
+           blind_levels + 1 < kMaxBlindLevels)
+      blind_levels++;
+    static const bool off = std::getenv("NOVA_HIP_BVH_NO_BLIND") != nullptr; // A/B
+    if (off) blind_levels = 0;
+  }
 
   std::vector<uint32_t> level_start { 0u };
   uint32_t ls = 0, le = 1; // nodes of the current level
   int cur = 0;
   size_t peak_bins = 0;
   for (uint32_t depth = 0;; depth++) {
+    const bool blind = depth < blind_levels;
+    if (!blind && depth == blind_levels && blind_levels > 0) {
+      // take over: lv[d] .. lv[d + 1] = level d for d <= depth; a level without nodes = the tree ended before it
+      BVHB_TRY(hipMemcpyAsync(h_total + 16, d_lv, (depth + 2) * 4, hipMemcpyDeviceToHost, stream));
+      BVHB_TRY(hipStreamSynchronize(stream));
+      const uint32_t* lv = h_total + 16;
+      uint32_t last = 0; // deepest level that has nodes
+      while (last < depth && lv[last + 2] > lv[last + 1]) last++;
+      level_start.assign(lv, lv + last + 1);
+      ls = lv[last];
+      le = lv[last + 1];
+      if (last < depth) { // ended inside the blind levels (its last level split nothing)
+        level_start.push_back(le);
+        break;
+      }
+    }
     level_start.push_back(le);
-    const uint32_t m = le - ls;
+    const uint32_t m = blind ? (1u << depth) : le - ls; // blind: an upper bound
+    const uint32_t* lvp = blind ? d_lv + depth : nullptr;
     const uint32_t num_bins = static_cast<uint32_t>(kMaxBins / static_cast<float>(depth + 1)); // bvh.cpp:145
     if (num_bins <= 1) break;
     BVHB_TRY(flags.reserve(static_cast<size_t>(m) * 4));
@@ -1963,7 +2014,7 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     if (fused_level) {
       k_level_setup<<<1, kScanBlock, 0, stream>>>(nodes.as<BNode>(), ls, m, depth >= kSmallMinDepth ? small_tris : 0u, num_bins,
                                                  chunk, all_multi, slots.as<Slot>(), item_base.as<uint32_t>(), d_n_slots, d_n_items,
-                                                 d_multi_count, multi_list.as<uint32_t>(), d_multi_count + 1);
+                                                 d_multi_count, multi_list.as<uint32_t>(), d_multi_count + 1, lvp);
     } else {
       BVHB_TRY(hipMemsetAsync(d_multi_count, 0, 8, stream));
       BVHB_TRY(hipMemsetAsync(items.p, 0, static_cast<size_t>(m) * 4, stream)); // nodes that are not split: no items
@@ -2003,7 +2054,8 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
     // flags / ranks are reused per slot from here on (n_slots <= m)
     if (fused_level) {
       k_choose_scan<<<1, kScanBlock, 0, stream>>>(slots.as<Slot>(), d_n_slots, nodes.as<BNode>(), axis_best.as<AxisBest>(),
-                                                 choice.as<Choice>(), ranks.as<uint32_t>(), d_total);
+                                                 choice.as<Choice>(), ranks.as<uint32_t>(), d_total,
+                                                 blind ? d_lv + depth : nullptr);
     } else {
       k_choose<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, n_slots, nodes.as<BNode>(),
                                                 axis_best.as<AxisBest>(), choice.as<Choice>(), flags.as<uint32_t>());
@@ -2011,33 +2063,37 @@ inline int build(hipStream_t stream, const float* d_verts, uint32_t n, nova_bvh_
       if (rc) return rc;
     }
     uint32_t n_split = 0;
-    rc = read_total(&n_split);
-    if (rc) return rc;
-    if (n_split == 0) break;
-    if (static_cast<uint64_t>(le) + 2ull * n_split > cap) return NOVA_HIP_E_BAD_SCENE; // cannot happen
+    if (!blind) {
+      rc = read_total(&n_split);
+      if (rc) return rc;
+      if (n_split == 0) break;
+      if (static_cast<uint64_t>(le) + 2ull * n_split > cap) return NOVA_HIP_E_BAD_SCENE; // cannot happen
+    }
     k_make_children<<<grid(n_slots), kB, 0, stream>>>(slots.as<Slot>(), d_n_slots, nodes.as<BNode>(),
                                                      axis_best.as<AxisBest>(), choice.as<Choice>(),
-                                                     ranks.as<uint32_t>(), le);
+                                                     ranks.as<uint32_t>(), le, lvp);
     const uint32_t gl_blocks = (n + kScanTile - 1) / kScanTile;
     if (gl_blocks > 8) { // the flags are made inside the scan's first pass
       BVHB_TRY(scan.sums.reserve(static_cast<size_t>(gl_blocks) * 4));
       k_gl_scan_reduce<<<gl_blocks, kScanBlock, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls,
                                                             choice.as<Choice>(), pbins.as<uint32_t>(), gl.as<uint32_t>(),
-                                                            scan.sums.as<uint32_t>());
+                                                            scan.sums.as<uint32_t>(), lvp);
       k_scan_sums<<<1, kScanBlock, 0, stream>>>(scan.sums.as<uint32_t>(), gl_blocks, d_total);
       k_scan_apply<<<gl_blocks, kScanBlock, 0, stream>>>(gl.as<uint32_t>(), n, scan.sums.as<uint32_t>(), gls.as<uint32_t>());
     } else {
       k_goes_left<<<grid(n), kB, 0, stream>>>(node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(), ls, choice.as<Choice>(),
-                                             pbins.as<uint32_t>(), gl.as<uint32_t>());
+                                             pbins.as<uint32_t>(), gl.as<uint32_t>(), lvp);
       rc = scan.run(gl.as<uint32_t>(), n, gls.as<uint32_t>());
       if (rc) return rc;
     }
     k_scatter<<<grid(n), kB, 0, stream>>>(order[cur].as<uint32_t>(), node_of[cur].as<uint32_t>(), n, nodes.as<BNode>(),
                                          ls, choice.as<Choice>(), gl.as<uint32_t>(), gls.as<uint32_t>(),
-                                         order[cur ^ 1].as<uint32_t>(), node_of[cur ^ 1].as<uint32_t>());
+                                         order[cur ^ 1].as<uint32_t>(), node_of[cur ^ 1].as<uint32_t>(), lvp);
     cur ^= 1;
-    ls = le;
-    le += 2 * n_split;
+    if (!blind) {
+      ls = le;
+      le += 2 * n_split;
+    }
   }
   // level_start[d] .. level_start[d + 1] are the nodes of depth d of the top of the tree
   const uint32_t n_top = le;

@@ -95,6 +95,23 @@ def test_degenerate_inputs():
     assert_same_tree(quad / np.float32(64.0))
 
 
+def test_trees_that_end_inside_the_blind_levels():
+    """From 4096 triangles on, the first levels of a build are enqueued without the host knowing how many nodes they
+    hold (bvh_build.hpp: blind levels, as many as log2(n / 2048) promises).  A tree that stops splitting sooner
+    must come out the same: the levels enqueued past its end find no nodes."""
+    one = S.soup(1, seed=3, edge=0.3)
+    # 30 000 copies of one triangle: the root is a leaf, three blind levels run on nothing
+    host, _ = assert_same_tree(np.repeat(one, 30000, axis=0))
+    assert len(host.bvh) == 1
+    # one split, then two unsplittable halves
+    two = np.concatenate([np.repeat(one, 20000, axis=0), np.repeat(one + np.float32(1.5), 20000, axis=0)])
+    host, _ = assert_same_tree(two)
+    assert len(host.bvh) == 3
+    # a small splittable part beside a big unsplittable one: the levels thin out long before log2(n / 2048)
+    mixed = np.concatenate([np.repeat(one, 60000, axis=0), S.soup(3000, seed=8, edge=0.05)])
+    assert_same_tree(mixed)
+
+
 def test_full_size_frame_scene():
     """BASELINE config 2's stand-in (871 200 triangles): the same tree, and faster than the CPU."""
     host, stats = assert_same_tree(S.knot_mesh(660, 660))
