@@ -601,6 +601,7 @@ int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
 }
 
 constexpr int kWideLdsStack = 16;       // LDS stack entries per lane of k_traverse4 (16 KB per block)
+constexpr size_t kCacheResidentBytes = 256u << 20; // nodes + triangles up to this size are served by L2 / Infinity Cache
 constexpr int kWideBlocksPerCu = 5; // = the resident work-groups at 5 waves/SIMD (8 was 0-10 % slower on launches below 0.3 M rays)
 
 // k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
@@ -635,9 +636,17 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       case 7: NOVA_LAUNCH_P(8, 5, false, false, 3);  // no forking in the drain
       case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);  // 6 waves/SIMD (spills 5-9 registers)
       case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
-      default: NOVA_LAUNCH_P(16, 5, true, false, 3); // 88-96 VGPRs, no spills; 6 waves/SIMD (14) spills 5-9.  Refill at
-                                                     // 16 idle lanes (was 8; with the near-side cull of round 2: C3 -2.8 %,
-                                                     // C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16)
+      case 24: NOVA_LAUNCH_P(16, 5, true, false, 3); // leaf steps without helper lanes (A/B against the default)
+      default:
+        // 96 VGPRs; 6 waves/SIMD (14) spills more.  Refill at 16 idle lanes (was 8; with the near-side cull of round 2:
+        // C3 -2.8 %, C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16).  Leaf steps with helper lanes (traverse.hpp) where
+        // the scene fits the caches: 1080p frame 3.62 -> 3.50 ms, C3 17.0 -> 15.9, C5 13.3 -> 13.0; on the 0.6 GB soup
+        // of C4, where a step waits for HBM, the helpers' exchange only lengthens it (16.4 -> 17.7 ms): not there.
+        if (static_cast<size_t>(s.n_wide) * sizeof(Node128) + static_cast<size_t>(s.n_tris) * 48 > kCacheResidentBytes)
+          NOVA_LAUNCH_P(16, 5, true, false, 3);
+        if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
+        else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
+        return static_cast<int>(hipGetLastError());
     }
 #undef NOVA_LAUNCH_P
   }
@@ -1865,7 +1874,7 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   // large batches over a scene that does not fit the caches: bin the rays first (NOVA_HIP_OPT_SORT_RAYS)
   const size_t scene_bytes = static_cast<size_t>(scene->n_wide) * sizeof(Node128) + static_cast<size_t>(scene->n_tris) * 48;
   const bool sort = scene->wide != nullptr && g.opt_traversal == 0 && (g.opt_kernel == 0 || g.opt_kernel == 7 || g.opt_kernel == 14 || g.opt_kernel >= 20) &&
-                    (g.opt_sort_rays == 2 || (g.opt_sort_rays == 0 && num_rays >= (1u << 20) && scene_bytes > (256u << 20)));
+                    (g.opt_sort_rays == 2 || (g.opt_sort_rays == 0 && num_rays >= (1u << 20) && scene_bytes > kCacheResidentBytes));
   if (sort) {
     const uint32_t n = static_cast<uint32_t>(num_rays);
     const uint32_t n_keys = 1u << kRayKeyBits;
