@@ -1232,9 +1232,33 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
       } else {
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
+        if (!STAGED) {
+          // two triangles per round: the rounds of a leaf are a chain of dependent scalar loads (the kernel's bound), and
+          // the node's 16 scalar registers are free here
+          const uint32_t end = first + count;
+          for (uint32_t i = first; i < end; i += 2) {
+            const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform addresses
+            const float4* q = tris + 3 * static_cast<size_t>(min(i + 1u, A.n_tris - 1u));
+            const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = q[0], q1 = q[1], q2 = q[2];
+            if (in && alive) {
+              if (COUNT) n_tris++;
+              if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
+                if (anyhit) alive = false;
+                far_limit = fma_(h.t, kCullRel, h.t);
+              }
+            }
+            if (in && alive && i + 1u < end) {
+              if (COUNT) n_tris++;
+              if (woop(r, h, static_cast<int>(i + 1u), q0, q1, q2)) {
+                if (anyhit) alive = false;
+                far_limit = fma_(h.t, kCullRel, h.t);
+              }
+            }
+          }
+        } else
         for (uint32_t i = first; i < first + count; i++) {
           float4 m0, m1, m2;
-          if (STAGED) {
+          {
             // up to 21 triangles (63 x 16 B, contiguous) per vector load
             const uint32_t k = (i - first) % 21u;
             if (k == 0) {
@@ -1242,9 +1266,6 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
               if (lane < pieces) stage[lane] = tris[3 * static_cast<size_t>(i) + lane];
             }
             m0 = stage[3 * k]; m1 = stage[3 * k + 1]; m2 = stage[3 * k + 2];
-          } else {
-            const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform address
-            m0 = m[0]; m1 = m[1]; m2 = m[2];
           }
           if (in && alive) {
             if (COUNT) n_tris++;
