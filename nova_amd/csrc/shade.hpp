@@ -27,6 +27,8 @@ struct ImageView {
   // material_loader.cpp:69-76) — so the sampled values are bit-identical and the array is a quarter of the bytes.
   // lut[x] = float(x) / 255.0f (k_shade fills it in LDS with the same correctly rounded division).
   const uchar4* u8;
+  // (a generic pointer on purpose: an address_space(3) pointer is 4 bytes on the device and 8 on the host, and this
+  // struct is part of kernel arguments)
   const float* lut;
   bool edge; // CLAMP repeats the edge texel (NOVA_HIP_OPT_CLAMP_TO_EDGE) instead of reading 0 beyond the image
 };
@@ -87,7 +89,9 @@ NV_DEV float4 texel(const ImageView& im, int i, int j, int layer) {
   const size_t k = (static_cast<size_t>(layer) * im.h + j) * im.w + i;
   if (im.u8) {
     const uchar4 t = im.u8[k];
-    return make_float4(im.lut[t.x], im.lut[t.y], im.lut[t.z], im.lut[t.w]);
+    // the table is in LDS (k_shade): read it as LDS — through the generic pointer every look-up is a flat load
+    const float __attribute__((address_space(3)))* lut = (const float __attribute__((address_space(3)))*) im.lut;
+    return make_float4(lut[t.x], lut[t.y], lut[t.z], lut[t.w]);
   }
   return im.texels[k];
 }
@@ -226,15 +230,20 @@ struct Brdf {
     float est_t = max_(((ratio.x + ratio.y) + ratio.z) / 3.0f, 0.25f);
     M3 basis = transpose(create_basis(normal));
     float phi = (2.0f * kPi) * xi1;
+    // (both members are assigned once, after the branch: assigned inside it, the compiler sinks the stores into one
+    // store through a selected address and keeps four words of this struct in scratch memory)
+    V3 mn, id;
     if (xi0 <= est_t) {
       float theta = nova_atanf(roughness * __builtin_sqrtf(xi2 / (1.0f - xi2)));
-      m_normal = mul(basis, spherical(theta, phi));
-      in_dir = reflect(-out_dir, m_normal);
+      mn = mul(basis, spherical(theta, phi));
+      id = reflect(-out_dir, mn);
     } else {
       float theta = nova_acosf(__builtin_sqrtf(xi2));
-      in_dir = mul(basis, spherical(theta, phi));
-      m_normal = normalize(in_dir + out_dir);
+      id = mul(basis, spherical(theta, phi));
+      mn = normalize(id + out_dir);
     }
+    m_normal = mn;
+    in_dir = id;
     return in_dir;
   }
   NV_DEV void intermediates() { // brdf.hpp:134-159
