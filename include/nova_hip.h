@@ -292,10 +292,12 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
                         const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
                         nova_float4* hits, uint64_t num_rays);
 
-/* nova_hip_trace_rays for callers that cannot allocate.  No counterpart in the reference: it is for code
- * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments,
- * same kernels and bit-identical hits, but the call makes no hipMalloc / hipFree / event or any other
- * allocating call: the launch's queue heads and the traversal-stack entries beyond the LDS part live in
+/* nova_hip_trace_rays for callers that cannot allocate.  No counterpart in the reference: it is for tight
+ * serving loops and harnesses that forbid hipMalloc (and, for code that builds HIP graphs, for the part
+ * OUTSIDE a capture: the call is synchronous on the library's own stream — it enqueues there, not on the
+ * caller's, and waits with hipStreamSynchronize — so it must not be made while a stream capture is active).
+ * Same arguments, same kernels and bit-identical hits, but the call makes no hipMalloc / hipFree / event or
+ * any other allocating call: the launch's queue heads and the traversal-stack entries beyond the LDS part live in
  * a static device array of 32 MiB + 8 KiB that every GPU the library runs on holds until the process
  * ends.  Conditions: nova_hip_init has run; the traversal layout of (bvh, triangles) is already cached,
  * i.e. nova_hip_trace_rays, nova_hip_launch_raytrace or nova_hip_build_bvh_device has seen these buffers
@@ -309,7 +311,8 @@ int nova_hip_trace_rays_noalloc(const nova_triangle_data* triangles, const nova_
 
 /* ---------------------------------------------------------------------------------------------
  * Backend options and counters (no counterpart in the reference, which has neither a bounce
- * cap, a fixed seed nor ray counters; SURVEY.md §7 "Hard parts").  Options are per process.
+ * cap, a fixed seed nor ray counters; SURVEY.md §7 "Hard parts").  Options are per process: they survive
+ * nova_hip_shutdown (counters do not).
  * ------------------------------------------------------------------------------------------- */
 enum {
   NOVA_HIP_OPT_MAX_DEPTH = 1,   /* max path segments per sample; 0 = unbounded (reference) */
@@ -322,7 +325,9 @@ enum {
                                    tiles that its own pixels' bilinear reads weight with more than 0) and leave the
                                    rest of every image as it is; kernel_post_process and nova_hip_render_samples
                                    refuse anti_aliasing (FXAA reads across tiles): see nova_hip_tiles_pack */
-  NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* internal A/B switch between traversal kernel variants */
+  NOVA_HIP_OPT_TRAVERSE_KERNEL = 6, /* validation: 0 = production (persistent lanes on the four-wide tree; packet kernel for
+                                       camera rays), 6 / 11 = the batch kernels on the four-wide / box-pair tree,
+                                       12 = the packet kernel for every launch.  Same hits from all of them */
   NOVA_HIP_OPT_SORT_RAYS = 8,   /* nova_hip_trace_rays: bin the batch by origin cell and direction octant before tracing
                                    (same hits; fewer HBM lines per ray). 0 = for batches of >= 2^20 rays over scenes
                                    larger than 256 MB (default), 1 = never, 2 = always */
@@ -332,6 +337,9 @@ enum {
                                      cudaAddressModeClamp — the edge texel repeats (src/backend/cuda/types/flags.hpp:30).
                                      Only FXAA's taps at the outermost pixel ring can tell the difference.  The address mode is
                                      all the switch changes: CUDA's 9-bit filter weights are not modelled. */
+  NOVA_HIP_OPT_ALLOC_CALLS = 10, /* read-only (nova_hip_get_option): allocating HIP runtime calls the library has made so far
+                                    (hipMalloc / hipFree / pinned memory / event and stream creation); what
+                                    tests/test_zz_no_alloc.py checks nova_hip_trace_rays_noalloc against */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

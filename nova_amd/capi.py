@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("NOVA_HIP_LIB") or os.path.join(_HERE, "libnova_hip.so
 OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT_TRAVERSE_KERNEL, OPT_TUNE, OPT_SORT_RAYS = \
     1, 2, 3, 4, 5, 6, 7, 8
 OPT_CLAMP_TO_EDGE = 9
+OPT_ALLOC_CALLS = 10  # read-only
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 

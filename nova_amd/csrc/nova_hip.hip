@@ -5,6 +5,8 @@
 // point fails with NOVA_HIP_E_NO_DEVICE / the hipError_t.
 #include <hip/hip_runtime.h>
 
+#include "alloc_count.hpp" // first: wraps the allocating runtime calls of everything below
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -20,10 +22,10 @@
 #include "bvh_pack.hpp"
 #include "bvh_pack_device.hpp"
 #include "image_kernels.hpp"
+#include "kernel_args_check.hpp"
 #include "nova_hip.h"
 #include "shade.hpp"
 #include "traverse.hpp"
-#include "traverse_quad.hpp"
 
 using namespace nova_hip;
 
@@ -72,13 +74,6 @@ struct PackedScene {
   Node64* nodes = nullptr;
   Node128* wide = nullptr; // null when the input boxes are not nested (traverse.hpp)
   uint32_t n_wide = 0;
-  // quad-per-ray layout (traverse_quad.hpp); q_wide is null when it could not be built
-  NodeQ* q_wide = nullptr;
-  NodeQ* q_pair = nullptr;
-  TriQuad* q_tris = nullptr;
-  uint32_t* q_slot_tri = nullptr;
-  uint32_t n_tri_quads = 0;
-  bool quad_tried = false;
   uint32_t stack_need_wide = 0;
   uint32_t n_packed = 0;
   uint32_t n_tris = 0;
@@ -210,15 +205,8 @@ const Alloc* find_alloc(const void* p) {
 void free_scene(PackedScene& s) {
   (void) hipFree(s.nodes);
   (void) hipFree(s.wide);
-  (void) hipFree(s.q_wide);
-  (void) hipFree(s.q_pair);
-  (void) hipFree(s.q_tris);
-  (void) hipFree(s.q_slot_tri);
   s.nodes = nullptr;
   s.wide = nullptr;
-  s.q_wide = s.q_pair = nullptr;
-  s.q_tris = nullptr;
-  s.q_slot_tri = nullptr;
 }
 
 void drop_scenes_using(const void* p) {
@@ -334,94 +322,8 @@ int add_block_counters(const FrameBuffers& fb, uint64_t bc[4]) {
   return 0;
 }
 
-// ---- quad-per-ray layout (traverse_quad.hpp): both trees as child-major NodeQ arrays whose leaf
-// references count TriQuads, the triangles regrouped so that every leaf starts on a TriQuad, and
-// the slot -> original index table.  Slots follow the order of the original indices (leaves sorted
-// by their first triangle), which is what makes "lowest slot" the reference's tie-break; leaves
-// that overlap would break that, so such a scene keeps the one-ray-per-lane kernel (returns 0 with
-// s.q_wide left null).
-int build_quad_layout(const Packer& pk, const std::vector<Node128>& wide, PackedScene& s, const nova_triangle_data* tris) {
-  const size_t n_leaves = pk.leaves.size();
-  std::vector<uint32_t> order(n_leaves);
-  for (size_t i = 0; i < n_leaves; i++) order[i] = static_cast<uint32_t>(i);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pk.leaves[a].first < pk.leaves[b].first; });
-  std::vector<uint32_t> quad_of_first(s.n_tris, 0xFFFFFFFFu);
-  std::vector<uint32_t> slot_tri;
-  slot_tri.reserve(static_cast<size_t>(s.n_tris) + 3 * n_leaves);
-  uint32_t prev_end = 0;
-  for (uint32_t l : order) {
-    const LeafRec& L = pk.leaves[l];
-    if (L.first < prev_end) return 0; // overlapping leaves
-    prev_end = L.first + L.count;
-    quad_of_first[L.first] = static_cast<uint32_t>(slot_tri.size() / 4);
-    for (uint32_t i = 0; i < L.count; i++) slot_tri.push_back(L.first + i);
-    while (slot_tri.size() % 4 != 0) slot_tri.push_back(0xFFFFFFFFu);
-  }
-  const size_t n_quads = slot_tri.size() / 4;
-  if (n_quads == 0 || n_quads > (1u << 24)) return 0;
-  bool ok = true;
-  auto remap = [&](uint32_t ref) -> uint32_t {
-    if (ref == kEmptyRef || !(ref & kLeafBit)) return ref;
-    const uint32_t q = quad_of_first[ref & 0x00FFFFFFu];
-    if (q == 0xFFFFFFFFu) { ok = false; return kEmptyRef; }
-    return kLeafBit | (ref & 0x7F000000u) | q;
-  };
-  const float qnan = std::numeric_limits<float>::quiet_NaN();
-  std::vector<NodeQ> qw(wide.size());
-  for (size_t i = 0; i < wide.size(); i++) {
-    const Node128& w = wide[i];
-    const float lo[3][4] = { { w.lo[0].x, w.lo[0].y, w.lo[0].z, w.lo[0].w }, { w.lo[1].x, w.lo[1].y, w.lo[1].z, w.lo[1].w },
-                             { w.lo[2].x, w.lo[2].y, w.lo[2].z, w.lo[2].w } };
-    const float hi[3][4] = { { w.hi[0].x, w.hi[0].y, w.hi[0].z, w.hi[0].w }, { w.hi[1].x, w.hi[1].y, w.hi[1].z, w.hi[1].w },
-                             { w.hi[2].x, w.hi[2].y, w.hi[2].z, w.hi[2].w } };
-    for (int k = 0; k < 4; k++) {
-      qw[i].lo_ref[k] = make_float4(lo[0][k], lo[1][k], lo[2][k], __builtin_bit_cast(float, remap(w.ref[k])));
-      qw[i].hi_e[k] = make_float4(hi[0][k], hi[1][k], hi[2][k], w.e[k]);
-    }
-  }
-  std::vector<NodeQ> qp(pk.out.size());
-  for (size_t i = 0; i < pk.out.size(); i++) {
-    const Node64& nd = pk.out[i];
-    const bool second = pk.child_leaf[1][i] != -2; // -2: unused slot of the synthetic single-leaf root
-    const uint32_t r0 = remap(__builtin_bit_cast(uint32_t, nd.a.w));
-    const uint32_t r1 = second ? remap(__builtin_bit_cast(uint32_t, nd.b.w)) : kEmptyRef;
-    qp[i].lo_ref[0] = make_float4(nd.b.x, nd.b.y, nd.b.z, __builtin_bit_cast(float, r0));
-    qp[i].hi_e[0] = make_float4(nd.a.x, nd.a.y, nd.a.z, nd.c.w);
-    qp[i].lo_ref[1] = make_float4(nd.d.x, nd.d.y, nd.d.z, __builtin_bit_cast(float, r1));
-    qp[i].hi_e[1] = make_float4(nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-    for (int k = 2; k < 4; k++) {
-      qp[i].lo_ref[k] = make_float4(qnan, qnan, qnan, __builtin_bit_cast(float, kEmptyRef));
-      qp[i].hi_e[k] = make_float4(qnan, qnan, qnan, 0.0f);
-    }
-  }
-  if (!ok) return 0;
-  hipError_t e = hipMalloc(&s.q_wide, qw.size() * sizeof(NodeQ));
-  if (e == hipSuccess) e = hipMalloc(&s.q_pair, qp.size() * sizeof(NodeQ));
-  if (e == hipSuccess) e = hipMalloc(&s.q_tris, n_quads * sizeof(TriQuad));
-  if (e == hipSuccess) e = hipMalloc(&s.q_slot_tri, slot_tri.size() * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemcpy(s.q_wide, qw.data(), qw.size() * sizeof(NodeQ), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(s.q_pair, qp.data(), qp.size() * sizeof(NodeQ), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(s.q_slot_tri, slot_tri.data(), slot_tri.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    const uint32_t n_slots = static_cast<uint32_t>(slot_tri.size());
-    hipLaunchKernelGGL(k_pack_tri_quads, dim3((n_slots + 255) / 256), dim3(256), 0, g.stream,
-                       reinterpret_cast<const float4*>(tris), s.q_slot_tri, n_slots, reinterpret_cast<float4*>(s.q_tris));
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-  }
-  if (e != hipSuccess) {
-    (void) hipFree(s.q_wide); (void) hipFree(s.q_pair); (void) hipFree(s.q_tris); (void) hipFree(s.q_slot_tri);
-    s.q_wide = s.q_pair = nullptr;
-    s.q_tris = nullptr;
-    s.q_slot_tri = nullptr;
-    return static_cast<int>(e);
-  }
-  s.n_tri_quads = static_cast<uint32_t>(n_quads);
-  return 0;
-}
-
 int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
-                    bool want_quad, PackedScene& s);
+                    PackedScene& s);
 
 bool host_pack_only() {
   static const bool on = std::getenv("NOVA_HIP_HOST_PACK") != nullptr; // diagnostics
@@ -466,22 +368,18 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
   const Alloc* ab = find_alloc(bvh);
   const Alloc* at = find_alloc(tris);
   if (!ab || !at) return NOVA_HIP_E_UNKNOWN_BUFFER;
-  // the quad-per-ray layout is an experiment (opt_kernel 16-19): built only when asked for
-  const bool want_quad = g.opt_kernel >= 16 && g.opt_kernel <= 19;
   for (auto& s : g.scenes) {
-    if (s.bvh_ptr == bvh && s.tri_ptr == tris && s.bvh_version == ab->version && s.tri_version == at->version &&
-        (!want_quad || s.quad_tried)) {
+    if (s.bvh_ptr == bvh && s.tri_ptr == tris && s.bvh_version == ab->version && s.tri_version == at->version) {
       *out = &s;
       return 0;
     }
   }
   drop_scenes_using(bvh); // stale entries for a rewritten buffer
   PackedScene s;
-  // on the device where the array is a well-formed, nested tree (bvh_pack_device.hpp); else, and for the
-  // experimental quad layout, on the host
+  // on the device where the array is a well-formed, nested tree (bvh_pack_device.hpp); else on the host
   int rc = 1;
-  if (!host_pack_only() && !want_quad) rc = pack_scene_device(bvh, tris, ab, at, s);
-  if (rc == 1) rc = pack_scene_host(bvh, tris, ab, at, want_quad, s);
+  if (!host_pack_only()) rc = pack_scene_device(bvh, tris, ab, at, s);
+  if (rc == 1) rc = pack_scene_host(bvh, tris, ab, at, s);
   if (rc) return rc;
   g.scenes.push_back(s);
   *out = &g.scenes.back();
@@ -490,7 +388,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
 
 // The traversal layout of a FlatBVHNode[] in device memory, made on the host (bvh_pack.hpp)
 int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
-                    bool want_quad, PackedScene& s) {
+                    PackedScene& s) {
   const size_t n_nodes = ab->bytes / sizeof(nova_bvh_node);
   const size_t n_tris = at->bytes / sizeof(nova_triangle_data);
   if (n_nodes == 0 || n_tris == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -556,7 +454,6 @@ int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, co
     pk.out[n].c.w = e + e_round;
   }
 
-  s.quad_tried = want_quad;
   s.bvh_ptr = bvh;
   s.tri_ptr = tris;
   s.bvh_version = ab->version;
@@ -577,7 +474,6 @@ int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, co
     s.stack_need_wide = wb.stack_need;
     e = hipMalloc(&s.wide, wb.out.size() * sizeof(Node128));
     if (e == hipSuccess) e = hipMemcpy(s.wide, wb.out.data(), wb.out.size() * sizeof(Node128), hipMemcpyHostToDevice);
-    if (e == hipSuccess && want_quad) e = static_cast<hipError_t>(build_quad_layout(pk, wb.out, s, tris));
   }
   if (e != hipSuccess) {
     free_scene(s);
@@ -625,71 +521,26 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   A.rays_per_wave = (g.opt_tune & 0xFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFF) : 64u;
   const dim3 grid(blocks), block(256);
   if (s.wide != nullptr && g.opt_kernel != 6) {
-    // persistent lanes (production); A/B variants: 7, 14, 20
-#define NOVA_LAUNCH_P(RMIN, MINW, FORK, LAZY, TPS)                                                                                   \
-    do {                                                                                                                        \
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, RMIN, MINW, FORK, LAZY, TPS>), grid, block, 0, g.stream, A);  \
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, RMIN, MINW, FORK, LAZY, TPS>), grid, block, 0, g.stream, A);       \
-      return static_cast<int>(hipGetLastError());                                                                               \
-    } while (0)
-    switch (g.opt_kernel) {
-      case 7: NOVA_LAUNCH_P(8, 5, false, false, 3);  // no forking in the drain
-      case 14: NOVA_LAUNCH_P(8, 6, true, false, 3);  // 6 waves/SIMD (spills 5-9 registers)
-      case 20: NOVA_LAUNCH_P(8, 5, true, true, 3);
-      case 24: NOVA_LAUNCH_P(16, 5, true, false, 3); // leaf steps without helper lanes (A/B against the default)
-      default:
-        // 96 VGPRs; 6 waves/SIMD (14) spills more.  Refill at 16 idle lanes (was 8; with the near-side cull of round 2:
-        // C3 -2.8 %, C2 -1.2 %, C4 -1 %; 4 is slower, 24 / 32 as 16).  Leaf steps with helper lanes (traverse.hpp) where
-        // the scene fits the caches: 1080p frame 3.62 -> 3.50 ms, C3 17.0 -> 15.9, C5 13.3 -> 13.0; on the 0.6 GB soup
-        // of C4, where a step waits for HBM, the helpers' exchange only lengthens it (16.4 -> 17.7 ms): not there.
-        if (static_cast<size_t>(s.n_wide) * sizeof(Node128) + static_cast<size_t>(s.n_tris) * 48 > kCacheResidentBytes)
-          NOVA_LAUNCH_P(16, 5, true, false, 3);
-        // (with helpers the lanes that wait for rays are not idle: refill at 32 — 8 / 16 / 24 / 32 / 40 / 48 idle lanes
-        // measured 3.58 / 3.50 / 3.49 / 3.46 / 3.61 / 3.82 ms per 1080p sample)
-        if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 32, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
-        else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 32, 5, true, false, 3, true>), grid, block, 0, g.stream, A);
-        return static_cast<int>(hipGetLastError());
+    // Persistent lanes (production).  96 VGPRs, 5 waves/SIMD (6 spills).  Leaf steps with helper lanes (traverse.hpp)
+    // where the scene fits the caches: 1080p frame 3.62 -> 3.50 ms, C3 17.0 -> 15.9, C5 13.3 -> 13.0; on the 0.6 GB soup
+    // of C4, where a step waits for HBM, the helpers' exchange only lengthens it (16.4 -> 17.7 ms): there the plain
+    // leaf step with a refill at 16 idle lanes.  With helpers the lanes that wait for rays are not idle: refill at 32
+    // (8 / 16 / 24 / 32 / 40 / 48 idle lanes measured 3.58 / 3.50 / 3.49 / 3.46 / 3.61 / 3.82 ms per 1080p sample).
+    // The A/B history of the other variants (no forking, 6 waves/SIMD, two-round leaf loads, four lanes per ray) is in
+    // DESIGN.md §7 and profiles/; their code left the library in round 3.
+    const bool resident = static_cast<size_t>(s.n_wide) * sizeof(Node128) + static_cast<size_t>(s.n_tris) * 48 <= kCacheResidentBytes;
+    if (!resident) {
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, 5, false>), grid, block, 0, g.stream, A);
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, 5, false>), grid, block, 0, g.stream, A);
+    } else {
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 32, 5, true>), grid, block, 0, g.stream, A);
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 32, 5, true>), grid, block, 0, g.stream, A);
     }
-#undef NOVA_LAUNCH_P
+    return static_cast<int>(hipGetLastError());
   }
   if (count) hipLaunchKernelGGL((k_traverse4<kWideLdsStack, true>), grid, block, 0, g.stream, A);
   else hipLaunchKernelGGL((k_traverse4<kWideLdsStack, false>), grid, block, 0, g.stream, A);
   return static_cast<int>(hipGetLastError());
-}
-
-// k_traverse_q: four lanes per ray (traverse_quad.hpp)
-constexpr int kQuadLdsStack = 24; // LDS stack entries per ray (6 KB per block)
-
-int launch_traverse_quad(const PackedScene& s, TraverseArgs A, bool count) {
-  const uint32_t need = std::max(s.stack_need, s.stack_need_wide) + 1u;
-  const unsigned blocks = static_cast<unsigned>(g.num_cus * 8);
-  const size_t quads = static_cast<size_t>(blocks) * 64;
-  const size_t words = need > static_cast<uint32_t>(kQuadLdsStack) ? (need - kQuadLdsStack) * quads : 0;
-  if (words > g.spill_words) {
-    (void) hipStreamSynchronize(g.stream);
-    (void) hipFree(g.d_spill);
-    g.d_spill = nullptr;
-    g.spill_words = 0;
-    HIP_TRY(hipMalloc(&g.d_spill, words * sizeof(uint32_t)));
-    g.spill_words = words;
-  }
-  A.spill = g.d_spill;
-  A.rays_per_wave = (g.opt_tune & 0xFFFF) > 0 ? static_cast<uint32_t>(g.opt_tune & 0xFFFF) : 32u;
-  QuadArgs G { s.q_wide, s.q_pair, s.q_tris, s.q_slot_tri };
-  const dim3 grid(blocks), block(256);
-#define NOVA_LAUNCH_Q(RMIN, MINW)                                                                                  \
-  do {                                                                                                             \
-    if (count) hipLaunchKernelGGL((k_traverse_q<kQuadLdsStack, true, RMIN, MINW>), grid, block, 0, g.stream, A, G); \
-    else hipLaunchKernelGGL((k_traverse_q<kQuadLdsStack, false, RMIN, MINW>), grid, block, 0, g.stream, A, G);      \
-    return static_cast<int>(hipGetLastError());                                                                    \
-  } while (0)
-  switch (g.opt_kernel) {
-    case 17: NOVA_LAUNCH_Q(4, 8);
-    case 18: NOVA_LAUNCH_Q(1, 8);
-    case 19: NOVA_LAUNCH_Q(2, 7);
-    default: NOVA_LAUNCH_Q(2, 8);
-  }
-#undef NOVA_LAUNCH_Q
 }
 
 int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
@@ -708,32 +559,23 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   hipEvent_t e0 = nullptr;
   span_begin(&e0);
   int rc;
-  // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays —
-  // an 8x8-pixel batch per wave is coherent enough that the plain batch kernel on the box-pair tree
-  // is the fastest (measured).  11 = that batch kernel for every launch.
-  // 16-19 = k_traverse_q (four lanes per ray; measured slower) for every launch
-  const bool quad = cull && s.q_wide != nullptr && g.opt_kernel >= 16 && g.opt_kernel <= 19;
-  const bool base = g.opt_kernel == 0 || g.opt_kernel >= 15;  // 20, 21: k_traverse_p with two-round leaf loads
-  // 22 = the per-lane kernel for camera rays too (A/B)
-  const bool wide = cull && !quad && ((base && !coherent) || g.opt_kernel == 6 || g.opt_kernel == 7 || g.opt_kernel == 14 || g.opt_kernel == 22);
-  const bool packet = cull && !quad && g.opt_kernel != 22 && ((base && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  // production (opt_kernel 0): persistent lanes on the four-wide tree, except for camera rays — an 8x8-pixel batch
+  // per wave is coherent enough for the packet kernel.  Validation / regression switches kept:
+  // 6 = k_traverse4 (batch kernel on the four-wide tree), 11 = k_traverse (batch kernel on the box-pair tree),
+  // 12 = the packet kernel for every launch.
+  const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || g.opt_kernel == 6);
+  const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12);
   // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
   // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on
   // the 1080p frame: 3.79 -> 3.30 ms of traversal (each XCD's L2 then serves one part of the frame).
   // NOVA_HIP_OPT_TUNE bits 16+ override it for A/B runs (0x100 = all off).
   A.flags = (g.opt_tune >> 16) != 0 ? static_cast<uint32_t>(g.opt_tune >> 16) & 0xFFu : 0xDu;
-  if (quad) rc = launch_traverse_quad(s, A, count);
-  else if (packet) {
-    // production: node and triangles through the scalar cache; 13 = staged through LDS by a
-    // four-lane vector load instead (A/B: 0.79-0.82 ms vs 0.74-0.78 ms on the 1080p camera rays)
+  if (packet) {
+    // node and triangles through the scalar cache (the wave-uniform stack in registers instead of LDS made no
+    // difference: the kernel waits on the scalar loads of nodes, not on its stack)
     const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
-    if (g.opt_kernel != 13) {
-      // (the wave-uniform stack in registers instead of LDS — select on push, v_readlane on pop — made
-      // no difference: the kernel waits on the scalar loads of nodes, not on its stack)
-      if (count) hipLaunchKernelGGL((k_traverse_packet<true, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
-      else hipLaunchKernelGGL((k_traverse_packet<false, false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
-    } else if (count) hipLaunchKernelGGL((k_traverse_packet<true, true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
-    else hipLaunchKernelGGL((k_traverse_packet<false, true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    if (count) hipLaunchKernelGGL((k_traverse_packet<true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    else hipLaunchKernelGGL((k_traverse_packet<false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
     rc = static_cast<int>(hipGetLastError());
   } else if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
@@ -978,11 +820,18 @@ int nova_hip_shutdown(void) {
   for (hipEvent_t e : g.ev_pool) (void) hipEventDestroy(e);
   for (auto& pd : g_pending) pd = Pending {};
   // buffers from nova_hip_malloc belong to the caller and stay valid; the registry goes with them
+  // ... and so do the options: they are per process (include/nova_hip.h), not per device context.  Counters
+  // (rays, kernel times) are per context and start again at zero.
   std::unordered_map<const void*, Alloc> allocs = std::move(g.allocs);
   const uint64_t next_version = g.next_version;
+  const int64_t opts[9] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
+                            g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays };
   g = Ctx {};
   g.allocs = std::move(allocs);
   g.next_version = next_version;
+  g.opt_max_depth = opts[0]; g.opt_traversal = opts[1]; g.opt_count_work = opts[2];
+  g.opt_tile_rank = opts[3]; g.opt_tile_ranks = opts[4]; g.opt_kernel = opts[5];
+  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8];
   return 0;
 }
 
@@ -1128,7 +977,9 @@ int nova_hip_set_option(int option, int64_t value) {
     case NOVA_HIP_OPT_TILE_RANKS:
       if (value < 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_tile_ranks = value; return 0;
-    case NOVA_HIP_OPT_TRAVERSE_KERNEL: g.opt_kernel = value; return 0;
+    case NOVA_HIP_OPT_TRAVERSE_KERNEL:
+      if (value != 0 && value != 6 && value != 11 && value != 12) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_kernel = value; return 0;
     case NOVA_HIP_OPT_TUNE: g.opt_tune = value; return 0;
     case NOVA_HIP_OPT_SORT_RAYS:
       if (value < 0 || value > 2) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1152,6 +1003,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_TUNE: *value = g.opt_tune; return 0;
     case NOVA_HIP_OPT_SORT_RAYS: *value = g.opt_sort_rays; return 0;
     case NOVA_HIP_OPT_CLAMP_TO_EDGE: *value = g.opt_clamp_to_edge; return 0;
+    case NOVA_HIP_OPT_ALLOC_CALLS: *value = static_cast<int64_t>(g_alloc_calls.load()); return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1730,6 +1582,9 @@ int nova_hip_measure_device(nova_hip_device_rates* out) {
 }
 
 // ---- denoise hand-off ---------------------------------------------------------------------------
+// floats per plane slot: k_flatten3 / k_pack3 access the planes as float4, so every plane starts on 16 bytes
+static size_t denoise_stride(size_t pixels) { return (3 * pixels + 3) & ~static_cast<size_t>(3); }
+
 static int ensure_denoise_planes(size_t pixels) {
   if (g.denoise_pixels >= pixels) return 0;
   HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1737,7 +1592,7 @@ static int ensure_denoise_planes(size_t pixels) {
   (void) hipHostFree(g.h_denoise);
   g.d_denoise = g.h_denoise = nullptr;
   g.denoise_pixels = 0;
-  const size_t bytes = 4 * pixels * 3 * sizeof(float);
+  const size_t bytes = 4 * denoise_stride(pixels) * sizeof(float);
   HIP_TRY(hipMalloc(&g.d_denoise, bytes));
   hipError_t e = hipHostMalloc(&g.h_denoise, bytes, hipHostMallocDefault);
   if (e != hipSuccess) { (void) hipFree(g.d_denoise); g.d_denoise = nullptr; return static_cast<int>(e); }
@@ -1756,7 +1611,7 @@ int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* alb
   if (pixels >= (1ull << 32)) return NOVA_HIP_E_TOO_LARGE;
   rc = ensure_denoise_planes(pixels);
   if (rc) return rc;
-  const size_t stride = g.denoise_pixels * 3; // floats per plane slot (slots sized for the largest frame seen)
+  const size_t stride = denoise_stride(g.denoise_pixels); // floats per plane slot (slots sized for the largest frame seen)
   const nova_hip_image* src[3] = { color, albedo, normal };
   const unsigned blocks = static_cast<unsigned>(std::min<size_t>((pixels / 4 + 255) / 256 + 1, static_cast<size_t>(g.num_cus) * 8));
   for (int k = 0; k < 3; k++)
@@ -1765,7 +1620,7 @@ int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* alb
   HIP_TRY(hipGetLastError());
   // one copy for the three planes when they are adjacent (the usual case: the slots fit the frame exactly)
   if (g.denoise_pixels == pixels) {
-    HIP_TRY(hipMemcpyAsync(g.h_denoise, g.d_denoise, 3 * stride * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.h_denoise, g.d_denoise, (2 * stride + 3 * pixels) * sizeof(float), hipMemcpyDeviceToHost, g.stream));
   } else {
     for (int k = 0; k < 3; k++)
       HIP_TRY(hipMemcpyAsync(g.h_denoise + k * stride, g.d_denoise + k * stride, pixels * 3 * sizeof(float),
@@ -1785,7 +1640,7 @@ int nova_hip_denoise_write(nova_hip_image* color, uint32_t width, uint32_t heigh
   if (width == 0 || height == 0 || !float_image_ok(color, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
   const size_t pixels = static_cast<size_t>(width) * height;
   if (g.denoise_pixels < pixels || !g.h_denoise) return NOVA_HIP_E_INVALID_ARGUMENT; // nova_hip_denoise_read comes first
-  const size_t stride = g.denoise_pixels * 3;
+  const size_t stride = denoise_stride(g.denoise_pixels);
   HIP_TRY(hipMemcpyAsync(g.d_denoise + 3 * stride, g.h_denoise + 3 * stride, pixels * 3 * sizeof(float),
                          hipMemcpyHostToDevice, g.stream));
   const unsigned blocks = static_cast<unsigned>(std::min<size_t>((pixels / 4 + 255) / 256 + 1, static_cast<size_t>(g.num_cus) * 8));
@@ -1875,7 +1730,7 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   T.queue_head = queue_heads;
   // large batches over a scene that does not fit the caches: bin the rays first (NOVA_HIP_OPT_SORT_RAYS)
   const size_t scene_bytes = static_cast<size_t>(scene->n_wide) * sizeof(Node128) + static_cast<size_t>(scene->n_tris) * 48;
-  const bool sort = scene->wide != nullptr && g.opt_traversal == 0 && (g.opt_kernel == 0 || g.opt_kernel == 7 || g.opt_kernel == 14 || g.opt_kernel >= 20) &&
+  const bool sort = scene->wide != nullptr && g.opt_traversal == 0 && g.opt_kernel == 0 &&
                     (g.opt_sort_rays == 2 || (g.opt_sort_rays == 0 && num_rays >= (1u << 20) && scene_bytes > kCacheResidentBytes));
   if (sort) {
     const uint32_t n = static_cast<uint32_t>(num_rays);
@@ -1921,8 +1776,8 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
   return 0;
 }
 
-// nova_hip_trace_rays for callers that cannot allocate (HIP graph capture, serving loops): same kernels,
-// same arguments, but the queue heads and the stack-spill area live in the static `scratch` array, no
+// nova_hip_trace_rays for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc):
+// same kernels, same arguments, but the queue heads and the stack-spill area live in the static `scratch` array, no
 // timing events are made and the traversal layout must already be cached.  Calls that overlap on one
 // GPU race on `scratch`.
 int nova_hip_trace_rays_noalloc(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
@@ -2081,7 +1936,7 @@ int nova_hip_validate_scene_pack(const nova_bvh_node* bvh, const nova_triangle_d
       have = &s;
   if (!have) return NOVA_HIP_E_INVALID_ARGUMENT; // nothing cached for these buffers
   PackedScene ref;
-  rc = pack_scene_host(bvh, triangles, ab, at, false, ref);
+  rc = pack_scene_host(bvh, triangles, ab, at, ref);
   if (rc) return rc;
   uint64_t diff = 0;
   diff += have->n_packed != ref.n_packed;

@@ -28,7 +28,8 @@ struct ImageView {
   // lut[x] = float(x) / 255.0f (k_shade fills it in LDS with the same correctly rounded division).
   const uchar4* u8;
   // (a generic pointer on purpose: an address_space(3) pointer is 4 bytes on the device and 8 on the host, and this
-  // struct is part of kernel arguments)
+  // struct is part of kernel arguments — round 2's one GPU fault; kernel_args_check.hpp now asserts the
+  // layout of every by-value kernel argument in both compiler passes)
   const float* lut;
   bool edge; // CLAMP repeats the edge texel (NOVA_HIP_OPT_CLAMP_TO_EDGE) instead of reading 0 beyond the image
 };

@@ -234,32 +234,6 @@ NV_DEV bool woop(const RayState& r, HitState& h, int index, float4 mx, float4 my
   return true;
 }
 
-// woop() in two parts: the distance from the z row alone, then the rest (same operations, same order)
-NV_DEV float woop_t(const RayState& r, float4 mz) {
-  float oz = fma_(mz.x, r.o.x, fma_(mz.y, r.o.y, fma_(mz.z, r.o.z, mz.w)));
-  float dz = fma_(mz.x, r.d.x, fma_(mz.y, r.d.y, mz.z * r.d.z));
-  return -oz / dz;
-}
-NV_DEV bool woop_uv(const RayState& r, HitState& h, int index, float t, float4 mx, float4 my) {
-  if (t < 0.0f || !__builtin_isfinite(t)) return false;
-  if (t >= h.t) {
-    if (!(t == h.t && h.id >= 0 && index < h.id)) return false;
-  }
-  float ox = fma_(mx.x, r.o.x, fma_(mx.y, r.o.y, fma_(mx.z, r.o.z, mx.w)));
-  float oy = fma_(my.x, r.o.x, fma_(my.y, r.o.y, fma_(my.z, r.o.z, my.w)));
-  float dx = fma_(mx.x, r.d.x, fma_(mx.y, r.d.y, mx.z * r.d.z));
-  float dy = fma_(my.x, r.d.x, fma_(my.y, r.d.y, my.z * r.d.z));
-  float u = fma_(t, dx, ox);
-  float v = fma_(t, dy, oy);
-  float w = (1.0f - u) - v;
-  if (w < 0.0f || u < 0.0f || v < 0.0f) return false;
-  h.t = t;
-  h.u = u;
-  h.v = v;
-  h.id = index;
-  return true;
-}
-
 template <int STACK, bool CULL, bool COUNT>
 __device__ __forceinline__ void trace_one(const TraverseArgs& A, uint32_t (*stk)[64], uint32_t lane,
                                           float4 o4, float4 d4, HitState& h, uint32_t& n_nodes,
@@ -686,8 +660,10 @@ NV_DEV unsigned long long hit_key(const HitState& h) {
                    : ~0ull;
 }
 
-template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool FORK, bool LAZY = false, int TPS = kTrisPerStep, bool HELP = false>
+template <int SLDS, bool COUNT, int REFILL_MIN, int MIN_WAVES, bool HELP>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
+  constexpr bool FORK = true; // drain-mode forking (a build without it: 4.73 -> 4.02 ms per sample in round 1)
+  constexpr int TPS = kTrisPerStep;
   __shared__ uint32_t lds_stack[4][SLDS + 1][64]; // row SLDS: see HybridStack::push_upto3
   // FORK: records of the rays that were split among several lanes of the wave (index = the lane
   // that loaded the ray): best (t, index) key, its t bits / u / v, members still running
@@ -939,7 +915,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
       // best hit, tests them, and hands back what it accepted; the owner merges by (t, index) — the same minimum the
       // in-order tests find — and moves on by 2 x TPS triangles.  (A second helper for the third TPS triangles
       // measured the same: 3.497 vs 3.498 ms.)
-      static_assert(!(HELP && LAZY), "helpers use the one-round leaf step");
       if (HELP) {
         const bool is_leaf = (cur & kLeafBit) != 0;
         const bool want = is_leaf && ((cur >> 24) & 0x7Fu) >= static_cast<uint32_t>(TPS); // more than TPS triangles left
@@ -1018,40 +993,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
         bool finished = false;
-        if (LAZY) {
-          // Two rounds of loads: the z rows first (they give t), then the x and y rows of the
-          // triangles whose t can still win.  A vector load costs ~17 cycles of the CU's memory
-          // path plus ~0.7 per active lane (scripts/ubench_gather.hip), and most triangles of a
-          // leaf are rejected on t alone, so the second round runs with few lanes.
-          float4 tz[TPS];
-#pragma unroll
-          for (int k = 0; k < TPS; k++)
-            tz[k] = A.tris[3 * static_cast<size_t>(min(first + k, A.n_tris - 1u)) + 2];
-          float tt[TPS];
-          uint32_t cm = 0;
-#pragma unroll
-          for (int k = 0; k < TPS; k++) {
-            tt[k] = woop_t(r, tz[k]);
-            // superset of what the in-order tests below can accept (h.t only shrinks)
-            const bool cand = count > static_cast<uint32_t>(k) && !(tt[k] < 0.0f) && __builtin_isfinite(tt[k]) && tt[k] <= h.t;
-            cm |= cand ? (1u << k) : 0u;
-            if (COUNT && count > static_cast<uint32_t>(k)) n_tris++;
-          }
-          // candidates in index order; a lane rarely has more than one
-          while (cm != 0 && !finished) {
-            const uint32_t kc = static_cast<uint32_t>(__builtin_ctz(cm));
-            cm &= cm - 1u;
-            float t = tt[0];
-#pragma unroll
-            for (int k = 1; k < TPS; k++) t = kc == static_cast<uint32_t>(k) ? tt[k] : t;
-            const float4* m = A.tris + 3 * static_cast<size_t>(first + kc);
-            const float4 mx = m[0], my = m[1];
-            if (woop_uv(r, h, static_cast<int>(first + kc), t, mx, my)) {
-              finished = anyhit;
-              far_limit = fma_(h.t, kCullRel, h.t);
-            }
-          }
-        } else {
         float4 tm[TPS][3];
         // byte offsets (n_tris <= 2^24, so they fit 32 bits and the one product is a 24-bit multiply)
         const uint32_t off0 = __umul24(first, 48u), last_off = (A.n_tris - 1u) * 48u;
@@ -1077,7 +1018,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
               far_limit = fma_(h.t, kCullRel, h.t);
             }
           }
-        }
         }
         if (FORK && forked && h.id >= 0) atomicMin(&rec_key[fam], hit_key(h));
         if (!finished && count > static_cast<uint32_t>(TPS)) {
@@ -1142,14 +1082,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kPacketStack = 72; // box-pair tree depth <= 64 (checked at upload)
 
-template <bool COUNT, bool STAGED>
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const Node64* __restrict__ nodes,
                                                          const float4* __restrict__ tris) {
   __shared__ uint32_t pstack[4][kPacketStack][4];
-  __shared__ float4 pstage[4][64]; // STAGED: a node (4 x 16 B) or up to 21 triangles, loaded once per wave
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t (*stk)[4] = pstack[threadIdx.x >> 6];
-  float4* stage = pstage[threadIdx.x >> 6];
   const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
   const uint32_t total = n * A.kinds;
   uint32_t n_nodes = 0, n_tris = 0;
@@ -1193,15 +1131,8 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
     while (act != 0) {
       const bool in = ((act >> lane) & 1ull) != 0;
       if (!(cur & kLeafBit)) {
-        float4 na, nb, nc, ndd;
-        if (STAGED) {
-          // four lanes fetch the 64-byte node (one coalesced quad), everyone reads it back from LDS
-          if (lane < 4) stage[lane] = reinterpret_cast<const float4*>(nodes + cur)[lane];
-          na = stage[0]; nb = stage[1]; nc = stage[2]; ndd = stage[3];
-        } else {
-          const Node64* nd = nodes + cur; // wave-uniform address
-          na = nd->a; nb = nd->b; nc = nd->c; ndd = nd->d;
-        }
+        const Node64* nd = nodes + cur; // wave-uniform address: scalar loads
+        const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
         if (COUNT) n_nodes += in ? 1u : 0u;
         float tmin0, tmax0, tmin1, tmax1;
         bool h0 = slab(r, na, nb, tmin0, tmax0);
@@ -1232,44 +1163,24 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
       } else {
         const uint32_t first = cur & 0x00FFFFFFu;
         const uint32_t count = ((cur >> 24) & 0x7Fu) + 1u;
-        if (!STAGED) {
-          // two triangles per round: the rounds of a leaf are a chain of dependent scalar loads (the kernel's bound), and
-          // the node's 16 scalar registers are free here
-          const uint32_t end = first + count;
-          for (uint32_t i = first; i < end; i += 2) {
-            const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform addresses
-            const float4* q = tris + 3 * static_cast<size_t>(min(i + 1u, A.n_tris - 1u));
-            const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = q[0], q1 = q[1], q2 = q[2];
-            if (in && alive) {
-              if (COUNT) n_tris++;
-              if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
-                if (anyhit) alive = false;
-                far_limit = fma_(h.t, kCullRel, h.t);
-              }
-            }
-            if (in && alive && i + 1u < end) {
-              if (COUNT) n_tris++;
-              if (woop(r, h, static_cast<int>(i + 1u), q0, q1, q2)) {
-                if (anyhit) alive = false;
-                far_limit = fma_(h.t, kCullRel, h.t);
-              }
-            }
-          }
-        } else
-        for (uint32_t i = first; i < first + count; i++) {
-          float4 m0, m1, m2;
-          {
-            // up to 21 triangles (63 x 16 B, contiguous) per vector load
-            const uint32_t k = (i - first) % 21u;
-            if (k == 0) {
-              const uint32_t pieces = 3u * min(21u, first + count - i);
-              if (lane < pieces) stage[lane] = tris[3 * static_cast<size_t>(i) + lane];
-            }
-            m0 = stage[3 * k]; m1 = stage[3 * k + 1]; m2 = stage[3 * k + 2];
-          }
+        // two triangles per round: the rounds of a leaf are a chain of dependent scalar loads (the kernel's bound), and
+        // the node's 16 scalar registers are free here.  (The node or the leaf staged through LDS by one vector load
+        // instead measured 0.79-0.82 vs 0.74-0.78 ms and 0.628 vs 0.622 ms: no gain, removed.)
+        const uint32_t end = first + count;
+        for (uint32_t i = first; i < end; i += 2) {
+          const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform addresses
+          const float4* q = tris + 3 * static_cast<size_t>(min(i + 1u, A.n_tris - 1u));
+          const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = q[0], q1 = q[1], q2 = q[2];
           if (in && alive) {
             if (COUNT) n_tris++;
             if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
+              if (anyhit) alive = false;
+              far_limit = fma_(h.t, kCullRel, h.t);
+            }
+          }
+          if (in && alive && i + 1u < end) {
+            if (COUNT) n_tris++;
+            if (woop(r, h, static_cast<int>(i + 1u), q0, q1, q2)) {
               if (anyhit) alive = false;
               far_limit = fma_(h.t, kCullRel, h.t);
             }

@@ -133,6 +133,7 @@ def test_shutdown_then_init_renders_again(cornell):
     first = rt.raytrace(3).copy()
     capi.check(capi.load().nova_hip_shutdown())
     capi.init(0)
-    capi.set_option(capi.OPT_MAX_DEPTH, 3)
+    assert capi.get_option(capi.OPT_MAX_DEPTH) == 3  # options are per process: they survive a shutdown
     rt.start()
     assert (rt.raytrace(3) == first).all()
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)

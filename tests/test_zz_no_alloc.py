@@ -33,7 +33,10 @@ def test_no_alloc_entry_point_equals_trace_rays_twice_in_a_row():
     ref1 = h_ref.read(np.uint32).reshape(n1, 4).copy()
     assert (ref1[:, 3].view(np.int32) >= 0).mean() > 0.2
     h_new.write(np.full((n1, 4), 0xDEADBEEF, np.uint32))
+    calls = capi.get_option(capi.OPT_ALLOC_CALLS)
+    assert calls > 0  # the counter works: the calls above allocated
     capi.trace_rays_noalloc(tb, bb, ro, rd, h_new, n1)
+    assert capi.get_option(capi.OPT_ALLOC_CALLS) == calls  # no hipMalloc / hipFree / event / stream made by the call
     _same(h_new.read(np.uint32).reshape(n1, 4), ref1, df)
     # second call, smaller input (other rays): stale queue heads or spill entries of the first would show
     pt2, df2 = random_rays(n2, seed=78, anyhit_every=4, tmax_every=2)
@@ -41,10 +44,21 @@ def test_no_alloc_entry_point_equals_trace_rays_twice_in_a_row():
     capi.trace_rays(tb, bb, ro2, rd2, h_ref, n2)
     ref2 = h_ref.read(np.uint32).reshape(n1, 4)[:n2].copy()
     h_new.write(np.full((n1, 4), 0xDEADBEEF, np.uint32))
+    calls = capi.get_option(capi.OPT_ALLOC_CALLS)
     capi.trace_rays_noalloc(tb, bb, ro2, rd2, h_new, n2)
+    assert capi.get_option(capi.OPT_ALLOC_CALLS) == calls
     got2 = h_new.read(np.uint32).reshape(n1, 4)
     _same(got2[:n2], ref2, df2)
     assert (got2[n2:] == 0xDEADBEEF).all()  # nothing written past the batch
+    # the validation kernels share the array too (none of them may grow the spill buffer)
+    for kernel in (6, 11, 12):
+        capi.set_option(capi.OPT_TRAVERSE_KERNEL, kernel)
+        h_new.write(np.full((n1, 4), 0xDEADBEEF, np.uint32))
+        calls = capi.get_option(capi.OPT_ALLOC_CALLS)
+        capi.trace_rays_noalloc(tb, bb, ro2, rd2, h_new, n2)
+        assert capi.get_option(capi.OPT_ALLOC_CALLS) == calls
+        _same(h_new.read(np.uint32).reshape(n1, 4)[:n2], ref2, df2)
+    capi.set_option(capi.OPT_TRAVERSE_KERNEL, 0)
     # argument errors come back as codes
     assert lib.nova_hip_trace_rays_noalloc(tb.ptr, bb.ptr, ro.ptr, rd.ptr, h_new.ptr, 1 << 31) == capi.E_TOO_LARGE
     assert lib.nova_hip_trace_rays_noalloc(tb.ptr, bb.ptr, 0x1000, rd.ptr, h_new.ptr, 16) == capi.E_UNKNOWN_BUFFER
