@@ -103,7 +103,10 @@ enum {
   NOVA_HIP_E_BAD_SCENE = -3,        /* BVH does not parse (child index out of range, ...) */
   NOVA_HIP_E_NO_DEVICE = -4,        /* no HIP device / device ordinal out of range */
   NOVA_HIP_E_TOO_LARGE = -5,        /* request exceeds a documented maximum */
-  NOVA_HIP_E_NOT_CACHED = -6        /* nova_hip_trace_rays_noalloc: no traversal layout cached for the buffers */
+  NOVA_HIP_E_NOT_CACHED = -6,       /* nova_hip_trace_rays_noalloc: no traversal layout cached for the buffers */
+  NOVA_HIP_E_NO_RCCL = -7,          /* nova_hip_tiles_comm_* / _allgather: librccl could not be opened */
+  NOVA_HIP_E_NO_COMM = -8,          /* nova_hip_tiles_allgather without a communicator */
+  NOVA_HIP_E_RCCL_BASE = -1000      /* an ncclResult_t r > 0 is returned as NOVA_HIP_E_RCCL_BASE - r */
 };
 const char* nova_hip_error_string(int code);
 
@@ -129,6 +132,12 @@ int nova_hip_shutdown(void);
  * ------------------------------------------------------------------------------------------- */
 int nova_hip_malloc(void** dev_ptr, size_t bytes);
 int nova_hip_free(void* dev_ptr);
+/* Page-locked host memory for the destinations of nova_hip_memcpy_d2h / nova_hip_image_read.  No counterpart in
+ * the reference, whose read_image2D / read_buffer return a fresh std::vector (src/backend/cuda/accelerator/
+ * accelerator.hpp:130-142, :213-219), i.e. a pageable copy every sample (src/core/raytracer.cpp:253-255): a caller
+ * that reads the frame back per sample keeps one such buffer instead. */
+int nova_hip_host_alloc(void** host_ptr, size_t bytes);
+int nova_hip_host_free(void* host_ptr);
 int nova_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int nova_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int nova_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes);
@@ -278,6 +287,37 @@ int nova_hip_denoise_write(nova_hip_image* color, uint32_t width, uint32_t heigh
 uint64_t nova_hip_tiles_stack_bytes(uint32_t width, uint32_t height, uint32_t ranks, uint32_t texel_bytes);
 int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev);
 int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev);
+
+/* The gather itself: RCCL (ncclAllGather over xGMI) behind the C ABI.  No counterpart in the reference, which has
+ * one device and no collective (src/backend/opencl/accelerator/accelerator.cpp:11-25); it is the per-rank hook a
+ * multi-process launch of Nova runs once per final frame, before image_utils::write_image
+ * (src/scene/scene.cpp:320-331; INTEGRATION.md §6, integration/multi_gpu_hook.cpp).  One process per GPU:
+ *   rank 0:      nova_hip_tiles_unique_id(id)            (ncclGetUniqueId; hand the 128 bytes to the other ranks by
+ *                                                          any means: a file, a socket, MPI, torch.distributed)
+ *   every rank:  nova_hip_tiles_comm_init(id, rank, n)   (ncclCommInitRank on the library's device; collective)
+ *                ... render with NOVA_HIP_OPT_TILE_RANK / _RANKS = rank / n ...
+ *   every rank:  nova_hip_tiles_allgather(image)         (pack -> ncclAllGather -> unpack on the library's stream:
+ *                                                          afterwards EVERY rank's image holds all ranks' tiles)
+ * A caller that already has an ncclComm_t hands it over with nova_hip_tiles_comm_adopt (the library then never
+ * destroys it).  librccl is opened on first use, from the directory of the HIP runtime the library is bound to
+ * (env NOVA_HIP_RCCL = full path overrides); single-GPU callers never load it.  The send and receive stacks are
+ * the library's own buffers, grown on demand.  With anti_aliasing gather temp_color2 (float4), set
+ * NOVA_HIP_OPT_TILE_RANKS = 1 on the rank that writes the frame and post-process there; without it post-process
+ * per rank and gather the uchar4 pixels. */
+#define NOVA_HIP_UNIQUE_ID_BYTES 128
+typedef struct {
+  uint32_t rank, ranks;   /* of the current communicator; ranks == 0: none */
+  int32_t device;         /* HIP device ordinal of the library's context */
+  int32_t rccl_version;   /* ncclGetVersion, 0 if librccl is not loaded */
+  char pci_bus_id[32];    /* hipDeviceGetPCIBusId of that device: distinct per rank on a multi-GPU node */
+  char rccl_path[256];    /* the librccl in use */
+} nova_hip_comm_info;
+int nova_hip_tiles_unique_id(void* id_out /* NOVA_HIP_UNIQUE_ID_BYTES */);
+int nova_hip_tiles_comm_init(const void* unique_id, uint32_t rank, uint32_t ranks);
+int nova_hip_tiles_comm_adopt(void* nccl_comm /* ncclComm_t */);
+int nova_hip_tiles_comm_destroy(void);
+int nova_hip_tiles_comm_info(nova_hip_comm_info* out);
+int nova_hip_tiles_allgather(nova_hip_image* image);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray batches.  find_intersection (kernels/raytrace.hpp:38-102) over an array of rays, for

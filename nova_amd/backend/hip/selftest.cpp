@@ -14,6 +14,7 @@
 
 #include "backend/hip/accelerator/accelerator.hpp"
 #include "backend/hip/bvh.hpp"
+#include "backend/hip/multi_gpu.hpp"
 
 using namespace nova;
 
@@ -203,6 +204,41 @@ int main(int argc, char** argv) {
           std::memcmp(fused_prev.data(), color_ref.data(), color_ref.size() * sizeof(float4)) != 0)
         throw std::runtime_error("render_samples differs from the per-sample schedule");
       std::cout << "render_samples OK" << std::endl;
+    }
+
+    // ---- the multi-GPU hook (backend/hip/multi_gpu.hpp) on a communicator of ONE rank: RCCL's all-gather is then a
+    // copy, so the frame must come back unchanged — through pack, ncclAllGather and unpack inside libnova_hip.so.
+    // (FXAA off: the uchar4 pixels travel; then with FXAA on: the float4 means travel and the frame is
+    // post-processed again, which must equal kernel_post_process with anti_aliasing on the same means.)
+    if (std::getenv("NOVA_SELFTEST_RCCL")) {
+      const std::string id_file = dir + "/rccl_id.bin";
+      std::remove(id_file.c_str());
+      multi_gpu::init_communicator(0, 1, id_file.c_str());
+      SceneParams plain = params[0];
+      reinterpret_cast<nova_scene_params&>(plain).anti_aliasing = 0;
+      kernel_post_process(dim3 {}, dim3 {}, plain, temp_color_img2.read_access().data(), color_img.data(), uint2 { width, height });
+      const auto before = accelerator.read_image2D(color_img, width, height);
+      multi_gpu::finish_frame(color_img.data(), temp_color_img2.write_access().data(), plain, uint2 { width, height }, 0, 1);
+      auto same_pixels = [](const std::vector<uchar4>& a, const std::vector<uchar4>& b) {
+        return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(uchar4)) == 0;
+      };
+      if (!same_pixels(accelerator.read_image2D(color_img, width, height), before)) throw std::runtime_error("one-rank gather changed the pixels");
+      SceneParams aa = params[0];
+      reinterpret_cast<nova_scene_params&>(aa).anti_aliasing = 1;
+      kernel_post_process(dim3 {}, dim3 {}, aa, temp_color_img2.read_access().data(), color_img.data(), uint2 { width, height });
+      const auto aa_before = accelerator.read_image2D(color_img, width, height);
+      const auto mean_before = accelerator.read_image2D(temp_color_img2, width, height);
+      const uchar4 zero {};
+      HIP_CHECK_AND_THROW(nova_hip_image_fill(color_img.data(), &zero));
+      multi_gpu::finish_frame(color_img.data(), temp_color_img2.write_access().data(), aa, uint2 { width, height }, 0, 1);
+      if (!same_pixels(accelerator.read_image2D(color_img, width, height), aa_before)) throw std::runtime_error("one-rank FXAA gather differs");
+      const auto mean_after = accelerator.read_image2D(temp_color_img2, width, height);
+      if (std::memcmp(mean_after.data(), mean_before.data(), mean_before.size() * sizeof(float4)) != 0)
+        throw std::runtime_error("one-rank gather changed the means");
+      nova_hip_comm_info info {};
+      HIP_CHECK_AND_THROW(nova_hip_tiles_comm_info(&info));
+      HIP_CHECK_AND_THROW(nova_hip_tiles_comm_destroy());
+      std::cout << "multi_gpu hook OK (RCCL " << info.rccl_version << ", " << info.rccl_path << ", device " << info.pci_bus_id << ")" << std::endl;
     }
 
     // a launch error must surface as nova::Error (cuda/accelerator/accelerator.hpp:28-29)

@@ -25,7 +25,7 @@ FILTER_NEAREST, FILTER_LINEAR = 0, 1
 EXPORTS = [
     "nova_hip_error_string", "nova_hip_init", "nova_hip_device_count", "nova_hip_device_name",
     "nova_hip_synchronize", "nova_hip_shutdown", "nova_hip_malloc", "nova_hip_free",
-    "nova_hip_memcpy_h2d", "nova_hip_memcpy_d2h", "nova_hip_memcpy_d2d", "nova_hip_fill",
+    "nova_hip_host_alloc", "nova_hip_host_free", "nova_hip_memcpy_h2d", "nova_hip_memcpy_d2h", "nova_hip_memcpy_d2d", "nova_hip_fill",
     "nova_hip_image_create", "nova_hip_image_destroy", "nova_hip_image_read",
     "nova_hip_image_write", "nova_hip_image_copy", "nova_hip_image_fill",
     "nova_hip_launch_raytrace", "nova_hip_launch_accumulate", "nova_hip_launch_post_process",
@@ -33,10 +33,14 @@ EXPORTS = [
     "nova_hip_reset_counters", "nova_hip_bvh_max_nodes", "nova_hip_build_bvh",
     "nova_hip_build_bvh_device", "nova_hip_validate_scene_pack",
     "nova_hip_tiles_stack_bytes", "nova_hip_tiles_pack", "nova_hip_tiles_unpack",
+    "nova_hip_tiles_unique_id", "nova_hip_tiles_comm_init", "nova_hip_tiles_comm_adopt",
+    "nova_hip_tiles_comm_destroy", "nova_hip_tiles_comm_info", "nova_hip_tiles_allgather",
     "nova_hip_denoise_read", "nova_hip_denoise_write", "nova_hip_measure_device",
 ]
 # error codes (include/nova_hip.h)
 E_INVALID_ARGUMENT, E_UNKNOWN_BUFFER, E_BAD_SCENE, E_NO_DEVICE, E_TOO_LARGE, E_NOT_CACHED = -1, -2, -3, -4, -5, -6
+E_NO_RCCL, E_NO_COMM, E_RCCL_BASE = -7, -8, -1000
+UNIQUE_ID_BYTES = 128
 
 
 class NovaHipError(RuntimeError):
@@ -91,6 +95,8 @@ def load() -> ctypes.CDLL:
         "nova_hip_shutdown": [],
         "nova_hip_malloc": [vp, sz],
         "nova_hip_free": [vp],
+        "nova_hip_host_alloc": [vp, sz],
+        "nova_hip_host_free": [vp],
         "nova_hip_memcpy_h2d": [vp, vp, sz],
         "nova_hip_memcpy_d2h": [vp, vp, sz],
         "nova_hip_memcpy_d2d": [vp, vp, sz],
@@ -119,6 +125,12 @@ def load() -> ctypes.CDLL:
         "nova_hip_denoise_write": [vp, u32, u32],
         "nova_hip_tiles_pack": [vp, u32, u32, vp],
         "nova_hip_tiles_unpack": [vp, u32, vp],
+        "nova_hip_tiles_unique_id": [vp],
+        "nova_hip_tiles_comm_init": [vp, u32, u32],
+        "nova_hip_tiles_comm_adopt": [vp],
+        "nova_hip_tiles_comm_destroy": [],
+        "nova_hip_tiles_comm_info": [vp],
+        "nova_hip_tiles_allgather": [vp],
     }
     lib.nova_hip_tiles_stack_bytes.restype = u64
     lib.nova_hip_tiles_stack_bytes.argtypes = [u32, u32, u32, u32]
@@ -256,6 +268,12 @@ class Image:
         check(load().nova_hip_image_read(self.handle, out.ctypes.data))
         return out[0] if self.layers == 1 else out
 
+    def read_into(self, host: "PinnedArray") -> np.ndarray:
+        """read_image2D into page-locked host memory the caller keeps (nova_hip_host_alloc)."""
+        assert host.nbytes >= self.width * self.height * self.layers * self.texel_bytes
+        check(load().nova_hip_image_read(self.handle, host.ptr))
+        return host.array
+
     def write(self, data: np.ndarray):
         data = np.ascontiguousarray(data)
         assert data.nbytes == self.width * self.height * self.layers * self.texel_bytes
@@ -281,6 +299,32 @@ class Image:
     def __del__(self):
         try:
             self.destroy()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory from nova_hip_host_alloc."""
+
+    def __init__(self, shape, dtype):
+        self.array = None
+        dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = ctypes.c_void_p()
+        check(load().nova_hip_host_alloc(ctypes.byref(p), self.nbytes))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                           shape=(self.nbytes,)).view(dtype).reshape(shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            check(load().nova_hip_host_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass
 
@@ -377,6 +421,42 @@ def tiles_pack(image: Image, rank: int, ranks: int, stack_ptr: int):
 def tiles_unpack(image: Image, ranks: int, stacks_ptr: int):
     """nova_hip_tiles_unpack: the all-gathered stacks at device pointer stacks_ptr into the whole image."""
     check(load().nova_hip_tiles_unpack(image.handle, ranks, stacks_ptr))
+
+
+class CommInfo(ctypes.Structure):
+    """nova_hip_comm_info (include/nova_hip.h)."""
+    _fields_ = [("rank", ctypes.c_uint32), ("ranks", ctypes.c_uint32), ("device", ctypes.c_int32),
+                ("rccl_version", ctypes.c_int32), ("pci_bus_id", ctypes.c_char * 32), ("rccl_path", ctypes.c_char * 256)]
+
+
+def tiles_unique_id() -> bytes:
+    """nova_hip_tiles_unique_id (rank 0): the 128 bytes of an ncclUniqueId, to be handed to every rank."""
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    check(load().nova_hip_tiles_unique_id(buf))
+    return buf.raw
+
+
+def tiles_comm_init(unique_id: bytes, rank: int, ranks: int):
+    """nova_hip_tiles_comm_init: ncclCommInitRank on the library's device (collective over the ranks)."""
+    assert len(unique_id) == UNIQUE_ID_BYTES
+    check(load().nova_hip_tiles_comm_init(ctypes.create_string_buffer(unique_id, UNIQUE_ID_BYTES), rank, ranks))
+
+
+def tiles_comm_destroy():
+    check(load().nova_hip_tiles_comm_destroy())
+
+
+def tiles_comm_info() -> dict:
+    c = CommInfo()
+    check(load().nova_hip_tiles_comm_info(ctypes.byref(c)))
+    return {"rank": c.rank, "ranks": c.ranks, "device": c.device, "rccl_version": c.rccl_version,
+            "pci_bus_id": c.pci_bus_id.decode(), "rccl_path": c.rccl_path.decode()}
+
+
+def tiles_allgather(image: Image):
+    """nova_hip_tiles_allgather: pack -> ncclAllGather -> unpack on the library's stream; afterwards every rank's
+    image holds every rank's tiles."""
+    check(load().nova_hip_tiles_allgather(image.handle))
 
 
 class BuildStats(ctypes.Structure):

@@ -4,6 +4,9 @@
 // gfx950 only.  No PyTorch, no CUDA shims, no CPU fallback: without a HIP device every entry
 // point fails with NOVA_HIP_E_NO_DEVICE / the hipError_t.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl is opened on first use (nova_hip_tiles_comm_*)
+
+#include <dlfcn.h>
 
 #include "alloc_count.hpp" // first: wraps the allocating runtime calls of everything below
 
@@ -15,6 +18,7 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -151,6 +155,13 @@ struct Ctx {
   float* d_denoise = nullptr;
   float* h_denoise = nullptr;
   size_t denoise_pixels = 0;
+  // RCCL gather of tile stacks (nova_hip_tiles_allgather): the communicator, whether the library made it, and the
+  // send / receive stacks
+  ncclComm_t comm = nullptr;
+  bool comm_owned = false;
+  uint32_t comm_rank = 0, comm_ranks = 0;
+  void* d_gather = nullptr;              // [send stack][ranks receive stacks]
+  size_t gather_bytes = 0;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -711,6 +722,77 @@ int ensure_tile_plan(uint32_t width, uint32_t height) {
   return 0;
 }
 
+
+// ---- RCCL, opened on first use ------------------------------------------------------------------
+// Single-GPU callers never load the 0.5 GB library.  It must be the librccl that belongs to the HIP runtime this
+// library is bound to — a process may hold two (PyTorch ships its own libamdhip64 + librccl next to ROCm's), and a
+// stream of one runtime means nothing to the other — so it is opened by path, in the directory hipMalloc lives in.
+struct Rccl {
+  bool tried = false, ok = false;
+  void* handle = nullptr;
+  char path[512] = {};
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+Rccl& rccl() {
+  static Rccl R;
+  return R;
+}
+bool load_rccl() {
+  Rccl& R = rccl();
+  if (R.tried) return R.ok;
+  R.tried = true;
+  std::string dir;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    dir = info.dli_fname;
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+  }
+  const char* env = std::getenv("NOVA_HIP_RCCL"); // full path of the library, for unusual installations
+  std::vector<std::string> tries;
+  if (env && *env) tries.push_back(env);
+  if (!dir.empty()) {
+    tries.push_back(dir + "librccl.so.1");
+    tries.push_back(dir + "librccl.so");
+  }
+  tries.push_back("librccl.so.1"); // the loader's own search (an already loaded copy, LD_LIBRARY_PATH, RUNPATH)
+  for (const std::string& t : tries) {
+    R.handle = dlopen(t.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (R.handle) {
+      std::snprintf(R.path, sizeof(R.path), "%s", t.c_str());
+      break;
+    }
+  }
+  if (!R.handle) return false;
+  R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(dlsym(R.handle, "ncclGetUniqueId"));
+  R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.handle, "ncclCommInitRank"));
+  R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.handle, "ncclCommDestroy"));
+  R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.handle, "ncclCommCount"));
+  R.CommUserRank = reinterpret_cast<decltype(R.CommUserRank)>(dlsym(R.handle, "ncclCommUserRank"));
+  R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.handle, "ncclAllGather"));
+  R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.handle, "ncclGetErrorString"));
+  R.GetVersion = reinterpret_cast<decltype(R.GetVersion)>(dlsym(R.handle, "ncclGetVersion"));
+  R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.CommCount && R.CommUserRank && R.AllGather &&
+         R.GetErrorString && R.GetVersion;
+  return R.ok;
+}
+const char* rccl_error_string(int nccl_code) {
+  if (rccl().ok) return rccl().GetErrorString(static_cast<ncclResult_t>(nccl_code));
+  return "nova_hip: RCCL error";
+}
+#define RCCL_TRY(expr)                                                     \
+  do {                                                                     \
+    ncclResult_t r_ = (expr);                                              \
+    if (r_ != ncclSuccess) return NOVA_HIP_E_RCCL_BASE - static_cast<int>(r_); \
+  } while (0)
+
 bool float_image_ok(const nova_hip_image* im, uint32_t w, uint32_t h) {
   return im && im->data && im->texel_bytes == 16 && im->width == w && im->height == h && im->layers >= 1;
 }
@@ -727,9 +809,12 @@ const char* nova_hip_error_string(int code) {
     case NOVA_HIP_E_BAD_SCENE: return "nova_hip: malformed BVH";
     case NOVA_HIP_E_NO_DEVICE: return "nova_hip: no usable HIP device";
     case NOVA_HIP_E_TOO_LARGE: return "nova_hip: request exceeds a documented maximum";
+    case NOVA_HIP_E_NO_RCCL: return "nova_hip: librccl could not be opened next to the HIP runtime in use, or lacks a symbol";
+    case NOVA_HIP_E_NO_COMM: return "nova_hip: no communicator (nova_hip_tiles_comm_init / _adopt comes first)";
     case NOVA_HIP_E_NOT_CACHED: return "nova_hip: no traversal layout cached for these buffers (an allocating call must see them first)";
     default: break;
   }
+  if (code <= NOVA_HIP_E_RCCL_BASE && code > NOVA_HIP_E_RCCL_BASE - 100) return rccl_error_string(NOVA_HIP_E_RCCL_BASE - code);
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
   return "nova_hip: unknown error";
 }
@@ -794,6 +879,8 @@ int nova_hip_shutdown(void) {
   for (auto& s : g.scenes) free_scene(s);
   g.scenes.clear();
   free_tile_plan();
+  if (g.comm && g.comm_owned && rccl().ok) (void) rccl().CommDestroy(g.comm);
+  (void) hipFree(g.d_gather);
   (void) hipFree(g.d_ray_keys);
   (void) hipFree(g.d_ray_perm);
   (void) hipFree(g.d_ray_hist);
@@ -854,6 +941,20 @@ int nova_hip_free(void* dev_ptr) {
   drop_scenes_using(dev_ptr);
   g.allocs.erase(it);
   HIP_TRY(hipFree(dev_ptr));
+  return 0;
+}
+
+int nova_hip_host_alloc(void** host_ptr, size_t bytes) {
+  if (!host_ptr || bytes == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+  return 0;
+}
+
+int nova_hip_host_free(void* host_ptr) {
+  if (!host_ptr) return 0;
+  HIP_TRY(hipHostFree(host_ptr));
   return 0;
 }
 
@@ -1658,12 +1759,11 @@ uint64_t nova_hip_tiles_stack_bytes(uint32_t width, uint32_t height, uint32_t ra
   return (n_tiles + ranks - 1) / ranks * (kTileSize * kTileSize) * texel_bytes;
 }
 
-int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev) {
-  int rc = require_ctx();
-  if (rc) return rc;
-  if (!image || !image->data || !stack_dev || ranks == 0 || rank >= ranks || image->layers != 1 ||
-      (image->texel_bytes != 16 && image->texel_bytes != 4))
-    return NOVA_HIP_E_INVALID_ARGUMENT;
+static bool tile_image_ok(const nova_hip_image* image) {
+  return image && image->data && image->layers == 1 && (image->texel_bytes == 16 || image->texel_bytes == 4);
+}
+
+static int tiles_pack_async(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev) {
   const uint32_t tiles_x = (image->width + kTileSize - 1) / kTileSize, tiles_y = (image->height + kTileSize - 1) / kTileSize;
   const uint32_t n_tiles = tiles_x * tiles_y, per_rank = (n_tiles + ranks - 1) / ranks;
   const unsigned blocks = static_cast<unsigned>(std::min<size_t>(static_cast<size_t>(per_rank) * 16, static_cast<size_t>(g.num_cus) * 16));
@@ -1673,17 +1773,10 @@ int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ran
   else
     hipLaunchKernelGGL(k_tiles_pack<uint32_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<const uint32_t*>(image->data),
                        image->width, image->height, tiles_x, n_tiles, rank, ranks, per_rank, static_cast<uint32_t*>(stack_dev));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(g.stream));
-  return 0;
+  return static_cast<int>(hipGetLastError());
 }
 
-int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev) {
-  int rc = require_ctx();
-  if (rc) return rc;
-  if (!image || !image->data || !stacks_dev || ranks == 0 || image->layers != 1 ||
-      (image->texel_bytes != 16 && image->texel_bytes != 4))
-    return NOVA_HIP_E_INVALID_ARGUMENT;
+static int tiles_unpack_async(nova_hip_image* image, uint32_t ranks, const void* stacks_dev) {
   const uint32_t tiles_x = (image->width + kTileSize - 1) / kTileSize, tiles_y = (image->height + kTileSize - 1) / kTileSize;
   const uint32_t n_tiles = tiles_x * tiles_y, per_rank = (n_tiles + ranks - 1) / ranks;
   const unsigned blocks = static_cast<unsigned>(std::min<size_t>(static_cast<size_t>(per_rank) * ranks * 16, static_cast<size_t>(g.num_cus) * 16));
@@ -1693,7 +1786,136 @@ int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* sta
   else
     hipLaunchKernelGGL(k_tiles_unpack<uint32_t>, dim3(blocks), dim3(256), 0, g.stream, static_cast<uint32_t*>(image->data),
                        image->width, image->height, tiles_x, n_tiles, ranks, per_rank, static_cast<const uint32_t*>(stacks_dev));
-  HIP_TRY(hipGetLastError());
+  return static_cast<int>(hipGetLastError());
+}
+
+int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!tile_image_ok(image) || !stack_dev || ranks == 0 || rank >= ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
+  rc = tiles_pack_async(image, rank, ranks, stack_dev);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!tile_image_ok(image) || !stacks_dev || ranks == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
+  rc = tiles_unpack_async(image, ranks, stacks_dev);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+// ---- the gather itself: RCCL behind the C ABI ---------------------------------------------------
+int nova_hip_tiles_unique_id(void* id_out) {
+  if (!id_out) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!load_rccl()) return NOVA_HIP_E_NO_RCCL;
+  static_assert(sizeof(ncclUniqueId) == NOVA_HIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  RCCL_TRY(rccl().GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+static void drop_comm() {
+  if (g.comm && g.comm_owned && rccl().ok) (void) rccl().CommDestroy(g.comm);
+  g.comm = nullptr;
+  g.comm_owned = false;
+  g.comm_rank = g.comm_ranks = 0;
+}
+
+int nova_hip_tiles_comm_init(const void* unique_id, uint32_t rank, uint32_t ranks) {
+  if (!unique_id || ranks == 0 || rank >= ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!load_rccl()) return NOVA_HIP_E_NO_RCCL;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  drop_comm();
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  HIP_TRY(hipSetDevice(g.device)); // the communicator is made on the library's device
+  ncclComm_t c = nullptr;
+  RCCL_TRY(rccl().CommInitRank(&c, static_cast<int>(ranks), id, static_cast<int>(rank)));
+  g.comm = c;
+  g.comm_owned = true;
+  g.comm_rank = rank;
+  g.comm_ranks = ranks;
+  return 0;
+}
+
+int nova_hip_tiles_comm_adopt(void* nccl_comm) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!nccl_comm) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!load_rccl()) return NOVA_HIP_E_NO_RCCL;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  int n = 0, r = 0;
+  RCCL_TRY(rccl().CommCount(static_cast<ncclComm_t>(nccl_comm), &n));
+  RCCL_TRY(rccl().CommUserRank(static_cast<ncclComm_t>(nccl_comm), &r));
+  if (n <= 0 || r < 0 || r >= n) return NOVA_HIP_E_INVALID_ARGUMENT;
+  drop_comm();
+  g.comm = static_cast<ncclComm_t>(nccl_comm);
+  g.comm_owned = false; // the caller's: never destroyed here
+  g.comm_rank = static_cast<uint32_t>(r);
+  g.comm_ranks = static_cast<uint32_t>(n);
+  return 0;
+}
+
+int nova_hip_tiles_comm_destroy(void) {
+  if (!g.ready) return 0;
+  (void) hipStreamSynchronize(g.stream);
+  drop_comm();
+  return 0;
+}
+
+int nova_hip_tiles_comm_info(nova_hip_comm_info* out) {
+  if (!out) return NOVA_HIP_E_INVALID_ARGUMENT;
+  int rc = require_ctx();
+  if (rc) return rc;
+  std::memset(out, 0, sizeof(*out));
+  out->rank = g.comm_rank;
+  out->ranks = g.comm_ranks;
+  out->device = g.device;
+  HIP_TRY(hipDeviceGetPCIBusId(out->pci_bus_id, static_cast<int>(sizeof(out->pci_bus_id)), g.device));
+  if (load_rccl()) {
+    int v = 0;
+    if (rccl().GetVersion(&v) == ncclSuccess) out->rccl_version = v;
+    std::snprintf(out->rccl_path, sizeof(out->rccl_path), "%s", rccl().path);
+  }
+  return 0;
+}
+
+// pack -> ncclAllGather -> unpack, all on the library's stream (nothing to order against another stream); one
+// collective of equal-sized stacks.  Afterwards EVERY rank's image holds every rank's tiles: an all-gather hands the
+// stacks to everyone anyway, and the unpack is one streaming pass (4K float4: 0.13 GB).
+int nova_hip_tiles_allgather(nova_hip_image* image) {
+  int rc = require_ctx();
+  if (rc) return rc;
+  if (!tile_image_ok(image)) return NOVA_HIP_E_INVALID_ARGUMENT;
+  if (!g.comm) return NOVA_HIP_E_NO_COMM;
+  const uint32_t ranks = g.comm_ranks, rank = g.comm_rank;
+  const size_t stack = nova_hip_tiles_stack_bytes(image->width, image->height, ranks, image->texel_bytes);
+  const size_t need = stack * (static_cast<size_t>(ranks) + 1);
+  if (need > g.gather_bytes) {
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    (void) hipFree(g.d_gather);
+    g.d_gather = nullptr;
+    g.gather_bytes = 0;
+    HIP_TRY(hipMalloc(&g.d_gather, need));
+    g.gather_bytes = need;
+  }
+  char* send = static_cast<char*>(g.d_gather);
+  char* recv = send + stack;
+  rc = tiles_pack_async(image, rank, ranks, send);
+  if (rc) return rc;
+  RCCL_TRY(rccl().AllGather(send, recv, stack, ncclChar, g.comm, g.stream)); // rank r's stack lands at recv + r * stack
+  rc = tiles_unpack_async(image, ranks, recv);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));
   return 0;
 }

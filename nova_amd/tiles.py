@@ -8,10 +8,15 @@ replicated per GPU and NO communication per sample.  Once per displayed/final fr
 tiles are gathered to rank 0 with one collective (RCCL all_gather over equal-sized tile stacks;
 every peer has its own xGMI link to the root, so this is one hop).
 
-One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU
-tests).  The production path is ``finish_frame``: the C ABI packs a rank's tiles into one contiguous
-stack (``nova_hip_tiles_pack``), ONE all_gather moves the stacks, rank 0 scatters them into the whole
-image (``nova_hip_tiles_unpack``).  With FXAA the float4 running means are gathered and rank 0
+One process per GPU.  The production path is ``finish_frame(..., via="capi")``: ONE call of the C ABI,
+``nova_hip_tiles_allgather``, packs a rank's tiles into a contiguous stack, moves the stacks with
+``ncclAllGather`` (RCCL, linked by the library itself) and scatters them into the whole image, all on the
+library's stream — the same call a multi-process launch of Nova makes from C++.
+Its communicator is made by ``init_comm``: rank 0 draws an ncclUniqueId through the C ABI and
+``torch.distributed`` (plumbing) hands the 128 bytes to the other ranks.  ``via="torch"`` keeps round 2's
+path for rehearsals where several ranks share one GPU (RCCL refuses two ranks on a device): the C ABI packs
+(``nova_hip_tiles_pack``), ``torch.distributed.all_gather_into_tensor`` moves the stacks (``nccl`` or, through
+host memory, ``gloo``), rank 0 unpacks (``nova_hip_tiles_unpack``).  With FXAA the float4 running means are gathered and rank 0
 post-processes the whole frame (FXAA reads up to ~26 px across tile borders, reference
 ``kernels/anti_aliasing.hpp:99-116``); without it every rank post-processes its own pixels and the
 uchar4 pixels are gathered (a quarter of the bytes).  ``pack_tiles``/``unpack_tiles`` are the same
@@ -114,14 +119,31 @@ def gather_image(image, rank: int, ranks: int, coll_device: str = "cuda", group=
     capi.tiles_unpack(image, ranks, gathered.data_ptr())
 
 
-def finish_frame(rt, rank: int, ranks: int, coll_device: str = "cuda", group=None) -> bool:
-    """The final frame of a tile-partitioned render: afterwards rank 0's ``rt.color_img`` holds the whole
-    post-processed frame (returns True there).  ``rt`` is a nova_amd.raytracer.Raytracer whose running
-    mean (``temp_color_img2``) is up to date on this rank's tiles."""
+def init_comm(rank: int, ranks: int, group=None) -> None:
+    """The library's own RCCL communicator (``nova_hip_tiles_comm_init``) for ``finish_frame(via="capi")``:
+    rank 0 draws the unique id, ``torch.distributed`` broadcasts its 128 bytes.  Collective over the group."""
+    import torch.distributed as dist
+
     from . import capi
 
+    box = [capi.tiles_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    capi.tiles_comm_init(box[0], rank, ranks)
+
+
+def finish_frame(rt, rank: int, ranks: int, coll_device: str = "cuda", group=None, via: str = "torch") -> bool:
+    """The final frame of a tile-partitioned render: afterwards rank 0's ``rt.color_img`` holds the whole
+    post-processed frame (returns True there).  ``rt`` is a nova_amd.raytracer.Raytracer whose running
+    mean (``temp_color_img2``) is up to date on this rank's tiles.  ``via="capi"``: the gather is
+    ``nova_hip_tiles_allgather`` (after ``init_comm``); ``via="torch"``: ``gather_image``."""
+    from . import capi
+
+    if via == "capi":
+        gather = lambda image: capi.tiles_allgather(image)  # noqa: E731
+    else:
+        gather = lambda image: gather_image(image, rank, ranks, coll_device, group)  # noqa: E731
     if bool(rt.params["anti_aliasing"]):
-        gather_image(rt.temp_color_img2, rank, ranks, coll_device, group)
+        gather(rt.temp_color_img2)
         if rank == 0:
             capi.set_option(capi.OPT_TILE_RANKS, 1)  # the image is whole now
             try:
@@ -130,7 +152,7 @@ def finish_frame(rt, rank: int, ranks: int, coll_device: str = "cuda", group=Non
                 capi.set_option(capi.OPT_TILE_RANKS, ranks)
     else:
         rt.kernel_post_process()
-        gather_image(rt.color_img, rank, ranks, coll_device, group)
+        gather(rt.color_img)
     return rank == 0
 
 

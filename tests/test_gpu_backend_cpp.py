@@ -36,11 +36,14 @@ def test_cpp_accelerator_runs_the_reference_schedule(tmp_path, cornell, denoise)
         from tests.helpers import golden
         np.ascontiguousarray(golden("cornell_box.npz")["verts"], np.float32).tofile(os.path.join(d, "verts.bin"))
     env = dict(os.environ, NOVA_HIP_MAX_DEPTH="4")
+    if denoise:  # ... and runs the multi-GPU hook (backend/hip/multi_gpu.hpp) on a one-rank RCCL communicator
+        env["NOVA_SELFTEST_RCCL"] = "1"
     r = subprocess.run([EXE, d, str(w), str(h), str(samples), str(seed), str(denoise)], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "selftest OK" in r.stdout
     assert ("bvh build OK" in r.stdout) == bool(denoise)
+    assert ("multi_gpu hook OK" in r.stdout) == bool(denoise), r.stdout + r.stderr
 
     prev = [np.zeros((h, w, 4), np.float32) for _ in range(3)]
     for s in range(samples):

@@ -48,3 +48,22 @@ def test_three_ranks_strong_scaling_with_fxaa_gather_the_same_frame():
     assert "fireplace_room stand-in" in out["config"]["workload"]
     one = out["same_workload_one_gpu"]
     assert one["ms_per_step"] > 0 and abs(one["rays_per_step"] - out["rays_per_step"]) < 0.02 * out["rays_per_step"]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` — no torchrun, WORLD_SIZE unset — must start its ranks itself (a
+    child torch.distributed.run made before the parent touches the GPU), pass the JSON line through and return the
+    child's exit code.  On this one-GPU box the child is the rehearsal mode (two ranks share the device, gloo),
+    and the line says which devices the ranks saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NOVA_BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "448", "--height", "256", "--check-frame"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["frame_check"] is True
+    r = out["rccl"]
+    assert r["world_size"] == 2 and r["ranks_seen"] == 2 and len(r["device_per_rank"]) == 2
+    assert r["distinct_devices"] == 1 and "rehearsal" in r["note"]  # one GPU here; 8 distinct bus ids on the node
+    assert r["gather_ms"] > 0

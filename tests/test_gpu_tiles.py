@@ -137,3 +137,44 @@ def test_shutdown_then_init_renders_again(cornell):
     rt.start()
     assert (rt.raytrace(3) == first).all()
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
+
+
+def test_allgather_through_the_c_abi_on_a_one_rank_rccl_communicator(cornell):
+    """nova_hip_tiles_allgather = pack -> ncclAllGather -> unpack inside libnova_hip.so.  One GPU
+    can hold a communicator of one rank, where the all-gather is a copy: uchar4 and float4 images, with sizes that
+    are not multiples of the tile, must come back bit for bit, and a frame gathered this way must equal the plain
+    frame.  (The N-rank layout is the same pack / unpack pair the 2-, 3- and 8-rank tests above check.)"""
+    lib = capi.load()
+    im = capi.Image(200, 150, texel_bytes=4)
+    assert lib.nova_hip_tiles_allgather(im.handle) == capi.E_NO_COMM  # no communicator yet
+    uid = capi.tiles_unique_id()
+    assert len(uid) == capi.UNIQUE_ID_BYTES and any(uid)
+    capi.tiles_comm_init(uid, 0, 1)
+    info = capi.tiles_comm_info()
+    assert info["ranks"] == 1 and info["rank"] == 0 and info["rccl_version"] > 0
+    assert "rccl" in info["rccl_path"] and len(info["pci_bus_id"]) >= 7
+    rng = np.random.default_rng(12)
+    for (w, h, tb) in ((200, 150, 4), (200, 150, 16), (64, 64, 16), (1921, 1081, 4)):
+        data = (rng.integers(0, 256, (h, w, 4), dtype=np.uint8) if tb == 4
+                else rng.standard_normal((h, w, 4), dtype=np.float32))
+        img = capi.Image(w, h, texel_bytes=tb, data=data)
+        capi.tiles_allgather(img)
+        got = img.read()
+        assert (got.view(np.uint8) == data.view(np.uint8)).all(), (w, h, tb)
+    # a rendered frame through finish_frame(via="capi"), FXAA off and on, against the plain schedule
+    w, h = 320, 200
+    for aa in (False, True):
+        p = S.make_scene_params(S.Camera(width=w, height=h, **S.CORNELL_CAMERA), anti_aliasing=aa)
+        capi.set_option(capi.OPT_MAX_DEPTH, 3)
+        rt = Raytracer(0)
+        rt.set_scene(cornell, p, w, h)
+        rt.start()
+        for t in (5, 6):
+            plain = rt.raytrace(t).copy()
+        assert tiles.finish_frame(rt, 0, 1, via="capi") is True
+        assert (rt.color_img.read() == plain).all(), aa
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    capi.tiles_comm_destroy()
+    assert lib.nova_hip_tiles_allgather(im.handle) == capi.E_NO_COMM
+    assert lib.nova_hip_tiles_comm_init(None, 0, 1) == capi.E_INVALID_ARGUMENT
+    assert lib.nova_hip_tiles_comm_init(uid, 2, 2) == capi.E_INVALID_ARGUMENT
