@@ -509,7 +509,10 @@ int launch_traverse_t(const TraverseArgs& A, bool cull, bool count) {
 
 constexpr int kWideLdsStack = 16;       // LDS stack entries per lane of k_traverse4 (16 KB per block)
 constexpr size_t kCacheResidentBytes = 256u << 20; // nodes + triangles up to this size are served by L2 / Infinity Cache
-constexpr int kWideBlocksPerCu = 5; // = the resident work-groups at 5 waves/SIMD (8 was 0-10 % slower on launches below 0.3 M rays)
+#ifndef NOVA_P_MINWAVES
+#define NOVA_P_MINWAVES 5 // A/B builds only (build_ab/): waves per SIMD the persistent kernel is compiled for
+#endif
+constexpr int kWideBlocksPerCu = NOVA_P_MINWAVES; // = the resident work-groups at 5 waves/SIMD (8 was 0-10 % slower on launches below 0.3 M rays)
 
 // k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
 int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
@@ -541,11 +544,11 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
     // DESIGN.md §7 and profiles/; their code left the library in round 3.
     const bool resident = static_cast<size_t>(s.n_wide) * sizeof(Node128) + static_cast<size_t>(s.n_tris) * 48 <= kCacheResidentBytes;
     if (!resident) {
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, 5, false>), grid, block, 0, g.stream, A);
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, 5, false>), grid, block, 0, g.stream, A);
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, NOVA_P_MINWAVES, false>), grid, block, 0, g.stream, A);
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, NOVA_P_MINWAVES, false>), grid, block, 0, g.stream, A);
     } else {
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 32, 5, true>), grid, block, 0, g.stream, A);
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 32, 5, true>), grid, block, 0, g.stream, A);
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 32, NOVA_P_MINWAVES, true>), grid, block, 0, g.stream, A);
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 32, NOVA_P_MINWAVES, true>), grid, block, 0, g.stream, A);
     }
     return static_cast<int>(hipGetLastError());
   }
@@ -1052,7 +1055,10 @@ int nova_hip_image_write(nova_hip_image* image, const void* host_src) {
 int nova_hip_image_copy(nova_hip_image* dst, const nova_hip_image* src) {
   if (!dst || !src || !dst->data || !src->data || image_bytes(dst) != image_bytes(src))
     return NOVA_HIP_E_INVALID_ARGUMENT;
-  HIP_TRY(hipMemcpy(dst->data, src->data, image_bytes(dst), hipMemcpyDeviceToDevice));
+  int rc = require_ctx();
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst->data, src->data, image_bytes(dst), hipMemcpyDeviceToDevice, g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream));
   return 0;
 }
 

@@ -411,9 +411,13 @@ def aircraft_scene(sky_size=(1024, 512)) -> Scene:
     """BASELINE config 5 on its own asset, from the committed data fixture tests/golden/aircraft.npz
     (tests/golden/make_aircraft_fixture.py: assets/aircraft/aircraft.obj + the two JPEGs its MTL uses that
     are in the reference tree; the third, `E-45 _col.jpg`, is absent — .MISSING_LARGE_BLOBS — and replaced
-    by a seeded procedural albedo).  Layers as Model::process_mesh loads them (src/model/model.cpp:76-89):
-    per material its diffuse map (sRGB -> linear on uint8, material_loader.cpp:24-33) and its normal map;
-    uint8 -> float4 / 255 (material_loader.cpp:69-76).  Sky: the analytic stand-in (lakeside_4k.hdr absent)."""
+    by a seeded procedural albedo).  The layers are texels the REFERENCE'S OWN MaterialLoader made (compiled from
+    its files, oracle/_ref/libnova_ref_material.so: stb decode, flip, sRGB -> linear on uint8, stbir resize to the
+    mean size, material_loader.cpp:11-80), in the order Model::process_mesh loads them (src/model/model.cpp:76-89):
+    a 256 x 256 window of each 1792 x 1792 layer (the whole array is 205 MB; its SHA-256 is in the fixture);
+    uint8 -> float4 / 255 (material_loader.cpp:69-76).  Sky: sky_size = None -> the 128 x 64 texels the reference's
+    SkyLoader returned for a Radiance file of the analytic stand-in (lakeside_4k.hdr is absent); else the analytic
+    stand-in itself at that size."""
     z = np.load(os.path.join(_HERE, "..", "tests", "golden", "aircraft.npz"))
     d = {k: z[k] for k in ("pos", "nrm", "tex", "tri_v", "tri_t", "tri_n", "tri_m")}
     verts, meta, kept = assemble_mesh(d, tangents=True)
@@ -422,7 +426,8 @@ def aircraft_scene(sky_size=(1024, 512)) -> Scene:
     meta["diffuse_index"] = z["diffuse_layer"][mat]
     meta["normal_index"] = z["normal_layer"][mat]
     layers = (z["layers"].astype(np.float32) / np.float32(255.0)).astype(np.float32)
-    return build_scene(verts, meta=meta, materials=layers, sky=analytic_sky(*sky_size))
+    sky = np.ascontiguousarray(z["sky"], np.float32) if sky_size is None else analytic_sky(*sky_size)
+    return build_scene(verts, meta=meta, materials=layers, sky=sky)
 
 
 AIRCRAFT_CAMERA = dict(position=[-1.6, 0.9, 1.9], target=[0.0, 0.0, 0.0], up=[0.0, 1.0, 0.0], fovy=40.0)

@@ -126,7 +126,10 @@ def test_c5_aircraft_textures_normal_maps_and_sky():
     assert (prod.view(np.uint32) == walk.view(np.uint32)).all()
     assert np.isfinite(prod).all()
     del rt
-    # 256x144 with feature images against the oracle: texture look-ups (bilinear, REPEAT), TBN normal mapping, sky
+    # 256x144 with feature images against the oracle: texture look-ups (bilinear, REPEAT), TBN normal mapping, sky —
+    # here with the sky texels the reference's own SkyLoader made (tests/golden/aircraft.npz, make_aircraft_fixture.py)
+    sc = S.aircraft_scene(sky_size=None)
+    assert sc.sky.shape == (64, 128, 4)
     w, h = 256, 144
     p = S.make_scene_params(S.Camera(width=w, height=h, **S.AIRCRAFT_CAMERA), shading_metallic=0.6, shading_roughness=0.3)
     rt = Raytracer(0, denoise_available=True)
@@ -148,10 +151,15 @@ def test_c5_aircraft_textures_normal_maps_and_sky():
 
 def test_c5_eight_bit_material_layers_give_the_same_frame_bit_for_bit():
     """SURVEY §8f rank 4 (texture path): the layers uploaded as uchar4 (a quarter of the bytes) and converted
-    x / 255.0f at sampling time give exactly the frame of the reference's float4 array — and the oracle's."""
-    sc = S.aircraft_scene()
+    x / 255.0f at sampling time give exactly the frame of the reference's float4 array — and the oracle's.  Both
+    arrays are the reference loader's own output (a window of MaterialLoader::build's float4 array and the uint8
+    texels under it: tests/golden/aircraft.npz, tests/test_reference_pins.py), not stand-ins."""
+    from tests.helpers import golden
+    sc = S.aircraft_scene(sky_size=None)
     u8 = S.aircraft_layers_u8()
     assert (sc.materials == (u8.astype(np.float32) / np.float32(255.0))).all()
+    f4 = golden("aircraft.npz")["window_f4"]
+    assert (sc.materials[:, :64, :64].view(np.uint32) == f4.view(np.uint32)).all()  # = MaterialLoader::build's values
     w, h = 512, 288
     p = S.make_scene_params(S.Camera(width=w, height=h, **S.AIRCRAFT_CAMERA), shading_metallic=0.6, shading_roughness=0.3)
     capi.set_option(capi.OPT_MAX_DEPTH, 5)

@@ -94,3 +94,47 @@ def test_every_test_scenes_triangle_data_live_against_the_reference(name, reques
     fin = np.isfinite(ref).all(1)
     assert fin.mean() > 0.99
     assert (got[fin].view(np.uint32) == ref[fin].view(np.uint32)).all()
+
+
+# ---- the texture path: the reference's own MaterialLoader / SkyLoader --------------------
+def test_material_layers_are_the_reference_loaders_texels_and_u8_over_255_is_the_float4_bitwise():
+    """tests/golden/aircraft.npz holds what nova::MaterialLoader::build returned for the aircraft's textures
+    (oracle/ref_material.cpp: the reference's files compiled as they are): a uint8 window of every layer and a
+    float4 window of the array itself.  The 8-bit path of the backend uploads the uint8 texels and divides by 255.0f
+    at sampling time: that must be the reference's float4, bit for bit."""
+    z = golden("aircraft.npz")
+    u8, f4 = z["layers"], z["window_f4"]
+    assert u8.shape == (4, 256, 256, 4) and f4.shape == (4, 64, 64, 4) and tuple(z["full_dims"]) == (1792, 1792, 4)
+    conv = u8[:, :64, :64].astype(np.float32) / np.float32(255.0)  # material_loader.cpp:69-76
+    assert (conv.view(np.uint32) == f4.view(np.uint32)).all()
+    assert (S.aircraft_scene().materials[:, :64, :64].view(np.uint32) == f4.view(np.uint32)).all()
+    assert (u8[..., 3] == 255).all() and u8[..., :3].std() > 20  # opaque, and not a flat patch
+    # the sRGB -> linear step ran on the diffuse layers only (material_loader.cpp:24-33): the glass material uses the
+    # same JPEG as diffuse (srgb) and as normal map (not): layer 2 = uint8(pow(layer 3 / 255, 2.2) * 255), up to the
+    # resize in between (the conversion runs BEFORE stbir_resize_uint8)
+    assert list(z["layer_srgb"]) == [True, False, True, False]
+    a, b = u8[2, ..., :3].astype(np.float64), u8[3, ..., :3].astype(np.float64)
+    assert np.abs(a - np.power(b / 255.0, 2.2) * 255.0).mean() < 1.5
+    sky = z["sky"]
+    assert sky.shape == (64, 128, 4) and np.isfinite(sky).all() and sky[..., :3].max() > 1e4  # the sun after pow 2.2
+
+
+@needs_ref
+def test_the_aircraft_fixture_is_what_the_reference_loaders_give_now(tmp_path):
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_aircraft_fixture as M
+    if not os.path.exists(M.LIB):
+        pytest.skip("oracle/_ref/libnova_ref_material.so not built")
+    z = golden("aircraft.npz")
+    now = M.build(str(tmp_path))
+    assert str(now["full_sha256"]) == str(z["full_sha256"])
+    for k in ("layers", "window_f4", "sky", "diffuse_layer", "normal_layer"):
+        assert now[k].tobytes() == z[k].tobytes(), k
+    # SkyLoader flips vertically and applies pow(x, 2.2): the first row returned is the LAST row of the file
+    src = S.analytic_sky(128, 64)[..., :3]
+    got = z["sky"][..., :3]
+    back = np.power(np.maximum(got[::-1], 0), 1 / 2.2)
+    rel = np.abs(back - src) / np.maximum(src, 1e-3)
+    assert np.median(rel) < 0.01  # RGBE keeps 8 bits of mantissa
