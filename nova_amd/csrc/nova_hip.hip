@@ -336,11 +336,6 @@ int add_block_counters(const FrameBuffers& fb, uint64_t bc[4]) {
 int pack_scene_host(const nova_bvh_node* bvh, const nova_triangle_data* tris, const Alloc* ab, const Alloc* at,
                     PackedScene& s);
 
-bool packet4_off() {
-  static const bool off = std::getenv("NOVA_HIP_NO_PACKET4") != nullptr; // A/B: camera rays on the box-pair packet kernel
-  return off;
-}
-
 bool host_pack_only() {
   static const bool on = std::getenv("NOVA_HIP_HOST_PACK") != nullptr; // diagnostics
   return on;
@@ -583,7 +578,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   // 6 = k_traverse4 (batch kernel on the four-wide tree), 11 = k_traverse (batch kernel on the box-pair tree),
   // 12 = the packet kernel for every launch.
   const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || g.opt_kernel == 6);
-  const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12 || g.opt_kernel == 13);
+  const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12);
   // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
   // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on
   // the 1080p frame: 3.79 -> 3.30 ms of traversal (each XCD's L2 then serves one part of the frame).
@@ -591,19 +586,10 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   A.flags = (g.opt_tune >> 16) != 0 ? static_cast<uint32_t>(g.opt_tune >> 16) & 0xFFu : 0xDu;
   if (packet) {
     // node and triangles through the scalar cache (the wave-uniform stack in registers instead of LDS made no
-    // difference: the kernel waits on the scalar loads of nodes, not on its stack).  On the four-wide tree where the
-    // scene has one and its depth fits the kernel's stack (k_traverse_packet4: half the dependent node fetches);
-    // 12 = the box-pair packet kernel, 13 = the four-wide one, for every launch (validation).
+    // difference; nor did the same packet on the four-wide tree: profiles/r03_packet4_ab.txt)
     const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
-    const bool four = g.opt_kernel != 12 && s.wide != nullptr && !packet4_off() &&
-                      std::max(s.stack_need, s.stack_need_wide) + 8u <= static_cast<uint32_t>(kPacket4Stack);
-    if (four) {
-      if (count) hipLaunchKernelGGL((k_traverse_packet4<true>), grid, block, 0, g.stream, A, s.wide, A.nodes, A.tris);
-      else hipLaunchKernelGGL((k_traverse_packet4<false>), grid, block, 0, g.stream, A, s.wide, A.nodes, A.tris);
-    } else {
-      if (count) hipLaunchKernelGGL((k_traverse_packet<true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
-      else hipLaunchKernelGGL((k_traverse_packet<false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
-    }
+    if (count) hipLaunchKernelGGL((k_traverse_packet<true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
+    else hipLaunchKernelGGL((k_traverse_packet<false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
     rc = static_cast<int>(hipGetLastError());
   } else if (wide) rc = launch_traverse_wide(s, A, count);
   else rc = s.stack_need <= 32 ? launch_traverse_t<32>(A, cull, count) : launch_traverse_t<64>(A, cull, count);
@@ -1099,7 +1085,7 @@ int nova_hip_set_option(int option, int64_t value) {
       if (value < 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_tile_ranks = value; return 0;
     case NOVA_HIP_OPT_TRAVERSE_KERNEL:
-      if (value != 0 && value != 6 && value != 11 && value != 12 && value != 13) return NOVA_HIP_E_INVALID_ARGUMENT;
+      if (value != 0 && value != 6 && value != 11 && value != 12) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_kernel = value; return 0;
     case NOVA_HIP_OPT_TUNE: g.opt_tune = value; return 0;
     case NOVA_HIP_OPT_SORT_RAYS:

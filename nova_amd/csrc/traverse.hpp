@@ -1091,6 +1091,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
 #define NOVA_STEP_COUNT_TRI(x) (x)
 #define NOVA_STEP_COUNT_ROUND 0u
 #endif
+// (Round 3 measured the same packet on the FOUR-wide tree — two s_load_dwordx16 per step, four ballots, children
+// entered nearest first: 19.9 instead of 37.7 node steps per packet on the benchmark frame, bit-identical hits, and
+// the same 0.61 ms per launch at the same occupancy, slower at the 7 waves/SIMD its 105 scalar registers allow: the
+// wide step issues ~250 instructions where two of these issue 2 x 110 and moves the same two lines.  The kernel is
+// bound by each wave's own serial stream, not by the number of dependent loads.  profiles/r03_packet4_ab.txt; the
+// code is in the repository's history, commit "packet4".)
 constexpr int kPacketStack = 72; // box-pair tree depth <= 64 (checked at upload)
 
 template <bool COUNT>
@@ -1212,227 +1218,6 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
                             (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(stk[sp][2]))) << 32);
         act = mk & alive_mask;
       }
-    }
-    if (valid) A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
-  }
-  if (COUNT) {
-    unsigned long long a = n_nodes, b = n_tris;
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off);
-      b += __shfl_down(b, off);
-    }
-    if (lane == 0) {
-      atomicAdd(&A.work_counters[0], a);
-      atomicAdd(&A.work_counters[1], b);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_traverse_packet4: the camera-ray packet on the FOUR-wide tree (round 3).  k_traverse_packet waits on a chain of
-// dependent scalar loads, one 64-byte box-pair node per step (61 % of its wave cycles); a Node128
-// covers two levels of that tree, so the packet makes half the steps, each with four slab tests per lane.  The node
-// is still fetched with wave-uniform addresses (two s_load_dwordx16: no texture-path traffic), the four children's
-// hit masks are ballots, the children are entered nearest first by the distance the first lane that hits each of
-// them sees (a heuristic: the order changes work, never results), and up to three (reference, lane mask) entries
-// go to the wave-uniform LDS stack per step.  Each lane makes the decisions of trace_wide for its own ray — same
-// slab arithmetic on the same boxes, same widened cull against its own best hit — so the hits are those of every
-// other kernel here.  Lanes whose ray the four-wide tree is not exact for (non-finite 1/d or -o/d) walk the
-// box-pair tree afterwards, as a packet of their own, with k_traverse_packet's step.
-// ---------------------------------------------------------------------------------------------
-constexpr int kPacket4Stack = 104; // entries; the host checks the tree's need (3 per wide level, 1 per box-pair level) + 8
-
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_traverse_packet4(TraverseArgs A, const Node128* __restrict__ wide,
-                                                          const Node64* __restrict__ nodes, const float4* __restrict__ tris) {
-  __shared__ uint32_t pstack[4][kPacket4Stack][4];
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t (*stk)[4] = pstack[threadIdx.x >> 6];
-  const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds;
-  uint32_t n_nodes = 0, n_tris = 0;
-  const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
-  const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
-
-  RayQueue Q;
-  Q.init(total, 64u, (A.flags & 8u) ? (A.flags & 3u) : 0u);
-  while (true) {
-    Q.fill_window(A.queue_head, lane);
-    if (Q.dry) break;
-    const uint32_t w = Q.w_next + lane;
-    const bool valid = w < Q.w_end;
-    Q.w_next = Q.w_end;
-    size_t slot = 0;
-    RayState r = {};
-    HitState h = { 0.0f, 0.0f, 0.0f, -1 };
-    bool alive = false, anyhit = false, pair = false;
-    float slack_scale = 0.0f, far_limit = 0.0f;
-    if (valid) {
-      const uint32_t kind = w / n;
-      const uint32_t j = w - kind * n;
-      slot = static_cast<size_t>(kind) * A.stride + j;
-      const float4 o4 = A.ray_o[slot];
-      const float4 d4 = A.ray_d[slot];
-      h.t = o4.w;
-      if (!(o4.w < 0.0f)) {
-        ray_setup(o4, d4, r);
-        anyhit = (__float_as_uint(d4.w) & 1u) != 0;
-        const float probe = fma_(r.inv.x, 0.0f, fma_(r.inv.y, 0.0f, r.inv.z * 0.0f)) +
-                            fma_(r.nio.x, 0.0f, fma_(r.nio.y, 0.0f, r.nio.z * 0.0f));
-        pair = !(probe == 0.0f);
-        float tmin, tmax;
-        alive = slab(r, rt, rb, tmin, tmax);
-        const float o_inf = max_(__builtin_fabsf(r.o.x), max_(__builtin_fabsf(r.o.y), __builtin_fabsf(r.o.z)));
-        slack_scale = max_(__builtin_fabsf(r.inv.x), max_(__builtin_fabsf(r.inv.y), __builtin_fabsf(r.inv.z))) *
-                      max_(1.0f, o_inf * A.inv_radius);
-        far_limit = fma_(__builtin_fabsf(h.t), kCullRel, h.t);
-      }
-    }
-    // two rounds: the regular rays on the four-wide tree, then (rarely) the others on the box-pair tree
-    for (int round = 0; round < 2; round++) {
-      uint64_t act = __ballot(alive && (pair == (round == 1)));
-      const bool on_wide = round == 0;
-      uint32_t sp = 0;
-      uint32_t cur = 0;
-      while (act != 0) {
-        const bool in = ((act >> lane) & 1ull) != 0;
-        if (!(cur & kLeafBit)) {
-          if (on_wide) {
-            const float4* nd = reinterpret_cast<const float4*>(wide + cur); // wave-uniform address: scalar loads
-            const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5], es = nd[7];
-            const uint4 rf = *reinterpret_cast<const uint4*>(nd + 6);
-            if (COUNT) n_nodes += 2u * NOVA_STEP_COUNT_NODE(in);
-            // child k: kernels/intersection.hpp:40-52 on its box, then trace_wide's cull
-#define NOVA_P4_CHILD(K, C)                                                                                              \
-            bool hit##K;                                                                                                 \
-            uint32_t uk##K;                                                                                              \
-            {                                                                                                            \
-              const float t1x = fma_(hx.C, r.inv.x, r.nio.x), t1y = fma_(hy.C, r.inv.y, r.nio.y), t1z = fma_(hz.C, r.inv.z, r.nio.z); \
-              const float t2x = fma_(lx.C, r.inv.x, r.nio.x), t2y = fma_(ly.C, r.inv.y, r.nio.y), t2z = fma_(lz.C, r.inv.z, r.nio.z); \
-              const float tn = max_(min_(t1x, t2x), max_(min_(t1y, t2y), min_(t1z, t2z)));                               \
-              const float tf = min_(max_(t1x, t2x), min_(max_(t1y, t2y), max_(t1z, t2z)));                               \
-              const float e = es.C * slack_scale;                                                                        \
-              hit##K = in && (tn <= tf) && (tf + e >= 0.0f) && (tn - e <= far_limit);                                    \
-              uk##K = __float_as_uint(max_(tn, 0.0f)); /* non-negative floats order like their bits */                   \
-            }
-            NOVA_P4_CHILD(0, x)
-            NOVA_P4_CHILD(1, y)
-            NOVA_P4_CHILD(2, z)
-            NOVA_P4_CHILD(3, w)
-#undef NOVA_P4_CHILD
-            const uint64_t m0 = __ballot(hit0), m1 = __ballot(hit1), m2 = __ballot(hit2), m3 = __ballot(hit3);
-            const uint64_t any = m0 | m1 | m2 | m3;
-            if (any != 0) {
-              // Everything below is wave-uniform and written as integer arithmetic (no booleans: the compiler turns a
-              // uniform `a < b` that is used as a number into a VALU select + readfirstlane).
-              // Entry distance of each child as ONE lane sees it — the first lane that hits any child; for a child
-              // that lane itself misses, its slab entry is still how far away the box lies.  Misses sort last.
-              const int rep = __builtin_ctzll(any);
-              const uint32_t nz0 = min(static_cast<uint32_t>(__popcll(m0)), 1u), nz1 = min(static_cast<uint32_t>(__popcll(m1)), 1u),
-                             nz2 = min(static_cast<uint32_t>(__popcll(m2)), 1u), nz3 = min(static_cast<uint32_t>(__popcll(m3)), 1u);
-              const uint32_t k0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(uk0), rep)) | (nz0 - 1u);
-              const uint32_t k1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(uk1), rep)) | (nz1 - 1u);
-              const uint32_t k2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(uk2), rep)) | (nz2 - 1u);
-              const uint32_t k3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(uk3), rep)) | (nz3 - 1u);
-              const uint32_t n_hit = nz0 + nz1 + nz2 + nz3;
-              // lt(a, b) = 1 if a < b: the borrow of a 64-bit subtraction.  rank = number of children that come
-              // first (nearer; the lower slot on a tie)
-#define NOVA_LT(a, b) static_cast<uint32_t>((static_cast<unsigned long long>(a) - static_cast<unsigned long long>(b)) >> 63)
-              const uint32_t x10 = NOVA_LT(k1, k0), x20 = NOVA_LT(k2, k0), x30 = NOVA_LT(k3, k0), x21 = NOVA_LT(k2, k1),
-                             x31 = NOVA_LT(k3, k1), x32 = NOVA_LT(k3, k2);
-#undef NOVA_LT
-              const uint32_t r0 = x10 + x20 + x30;
-              const uint32_t r1 = (1u - x10) + x21 + x31;
-              const uint32_t r2 = (2u - x20 - x21) + x32;
-              const uint32_t r3 = 3u - x30 - x31 - x32;
-              // Rank 0 is entered now; ranks 1 .. n_hit-1 go to the stack, the farthest lowest, so the new stack
-              // pointer is sp + n_hit - 1.  A child of rank r is stored at sp + ((n_hit - 1 - r) & 7): for the pushed
-              // ones that is their place; rank 0 lands on the new top and the misses 5-7 entries above the old one,
-              // all of which lie above the valid part and are never read.
-              const uint32_t base = sp + n_hit - 1u;
-              if (lane == 0) {
-                uint4* s4 = reinterpret_cast<uint4*>(&stk[0][0]);
-                s4[sp + ((n_hit - 1u - r0) & 7u)] = make_uint4(rf.x, static_cast<uint32_t>(m0), static_cast<uint32_t>(m0 >> 32), 0u);
-                s4[sp + ((n_hit - 1u - r1) & 7u)] = make_uint4(rf.y, static_cast<uint32_t>(m1), static_cast<uint32_t>(m1 >> 32), 0u);
-                s4[sp + ((n_hit - 1u - r2) & 7u)] = make_uint4(rf.z, static_cast<uint32_t>(m2), static_cast<uint32_t>(m2 >> 32), 0u);
-                s4[sp + ((n_hit - 1u - r3) & 7u)] = make_uint4(rf.w, static_cast<uint32_t>(m3), static_cast<uint32_t>(m3 >> 32), 0u);
-              }
-              sp = base;
-              // the child of rank 0: masks by arithmetic as well (z = all ones where the rank is 0)
-              const uint32_t z0 = min(r0, 1u) - 1u, z1 = min(r1, 1u) - 1u, z2 = min(r2, 1u) - 1u, z3 = min(r3, 1u) - 1u;
-              cur = (rf.x & z0) | (rf.y & z1) | (rf.z & z2) | (rf.w & z3);
-              const uint64_t w0 = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(z0))),
-                             w1 = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(z1))),
-                             w2 = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(z2))),
-                             w3 = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(z3)));
-              act = (m0 & w0) | (m1 & w1) | (m2 & w2) | (m3 & w3);
-              continue;
-            }
-          } else {
-            const Node64* nd = nodes + cur; // wave-uniform address: scalar loads
-            const float4 na = nd->a, nb = nd->b, nc = nd->c, ndd = nd->d;
-            if (COUNT) n_nodes += NOVA_STEP_COUNT_NODE(in);
-            float tmin0, tmax0, tmin1, tmax1;
-            bool h0 = slab(r, na, nb, tmin0, tmax0);
-            bool h1 = slab(r, nc, ndd, tmin1, tmax1);
-            const float es = nc.w * slack_scale;
-            h0 = in && h0 && (tmax0 + es >= 0.0f) && (tmin0 - es <= far_limit);
-            h1 = in && h1 && (tmax1 + es >= 0.0f) && (tmin1 - es <= far_limit);
-            const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-            const uint32_t ref0 = __float_as_uint(na.w), ref1 = __float_as_uint(nb.w);
-            if (m0 != 0 && m1 != 0) {
-              const uint64_t both = m0 & m1;
-              const uint64_t second_nearer = __ballot(h0 && h1 && tmin1 < tmin0);
-              const bool swap = both != 0 ? (2 * __popcll(second_nearer) > __popcll(both)) : (__popcll(m1) > __popcll(m0));
-              const uint64_t far_mask = swap ? m0 : m1;
-              reinterpret_cast<uint4*>(&stk[0][0])[sp] = make_uint4(swap ? ref0 : ref1, static_cast<uint32_t>(far_mask),
-                                                                    static_cast<uint32_t>(far_mask >> 32), 0u);
-              sp++;
-              cur = swap ? ref1 : ref0;
-              act = swap ? m1 : m0;
-              continue;
-            }
-            if (m0 != 0) { cur = ref0; act = m0; continue; }
-            if (m1 != 0) { cur = ref1; act = m1; continue; }
-          }
-        } else {
-          const uint32_t first = cur & 0x00FFFFFFu;
-          const uint32_t end = first + ((cur >> 24) & 0x7Fu) + 1u;
-          for (uint32_t i = first; i < end; i += 2) { // two triangles per round, as in k_traverse_packet
-            const float4* m = tris + 3 * static_cast<size_t>(i); // wave-uniform addresses
-            const float4* q = tris + 3 * static_cast<size_t>(min(i + 1u, A.n_tris - 1u));
-            const float4 m0 = m[0], m1 = m[1], m2 = m[2], q0 = q[0], q1 = q[1], q2 = q[2];
-            if (COUNT) n_tris += NOVA_STEP_COUNT_ROUND;
-            if (in && alive) {
-              if (COUNT) n_tris += NOVA_STEP_COUNT_TRI(1u);
-              if (woop(r, h, static_cast<int>(i), m0, m1, m2)) {
-                if (anyhit) alive = false;
-                far_limit = fma_(h.t, kCullRel, h.t);
-              }
-            }
-            if (in && alive && i + 1u < end) {
-              if (COUNT) n_tris += NOVA_STEP_COUNT_TRI(1u);
-              if (woop(r, h, static_cast<int>(i + 1u), q0, q1, q2)) {
-                if (anyhit) alive = false;
-                far_limit = fma_(h.t, kCullRel, h.t);
-              }
-            }
-          }
-        }
-        // pop the next subtree some lane still wants
-        const uint64_t alive_mask = __ballot(alive);
-        act = 0;
-        while (sp != 0 && act == 0) {
-          --sp;
-          const uint4 e = reinterpret_cast<const uint4*>(&stk[0][0])[sp];
-          cur = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.x)));
-          // (through uint32_t: see k_traverse_packet — a sign-extended low word would switch lanes 32-63 on)
-          const uint64_t mk = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.y)))) |
-                              (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.z)))) << 32);
-          act = mk & alive_mask;
-        }
-      }
-      if (__ballot(alive && pair) == 0) break; // no second round: the usual case
     }
     if (valid) A.hits[slot] = make_float4(h.t, h.u, h.v, __int_as_float(h.id));
   }

@@ -12,7 +12,7 @@ rt = Raytracer(0)
 rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_COUNT_WORK, 1)
 packets = W * H / 64
-for kernel, name in ((12, "box-pair packet"), (13, "four-wide packet")):
+for kernel, name in ((12, "box-pair packet"),):  # (13 = the four-wide packet of commit "packet4": profiles/r03_packet_steps.txt)
     capi.set_option(capi.OPT_TRAVERSE_KERNEL, kernel)
     capi.reset_counters()
     rt.kernel_raytrace(1)

@@ -54,7 +54,7 @@ def gpu_primary_ids(sc, cam_kw, w, h, time, traversal=0, kernel=0):
     ("soup50k", "ids_soup_256.npz", SOUP_CAMERA, 256),
     ("knot_small", "ids_knot_256.npz", S.DRAGON_CAMERA, 256),
 ])
-@pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 6), (0, 11), (0, 12), (0, 13)])
+@pytest.mark.parametrize("traversal,kernel", [(0, 0), (1, 0), (0, 6), (0, 11), (0, 12)])
 def test_primary_hit_ids_match_the_golden_vectors(fixture, file, cam, size, traversal, kernel, request):
     sc = request.getfixturevalue(fixture)
     g = golden(file)
@@ -220,7 +220,7 @@ def test_packet_kernel_keeps_lane_masks_above_lane_31():
     walk = _trace(sc.triangles, sc.bvh, pt, df, traversal=1)
     ref = oracle().trace_rays(sc, pt, df).view(np.uint32)
     assert (walk == ref).all()
-    for kernel in (12, 13, 0, 11):  # 12 / 13 = the packet kernels (box-pair / four-wide tree) for every launch
+    for kernel in (12, 0, 11):  # 12 = the packet kernel for every launch
         got = _trace(sc.triangles, sc.bvh, pt, df, kernel=kernel)
         assert (got == ref).all(), kernel
 
@@ -276,7 +276,7 @@ def _irregular_rays(n, seed):
 
 
 @pytest.mark.parametrize("fixture", ["cornell", "knot_small", "soup50k"])
-@pytest.mark.parametrize("kernel", [0, 6, 11, 12, 13])  # 6 / 11 = batch kernels (four-wide / box-pair tree), 12 / 13 = packet kernels
+@pytest.mark.parametrize("kernel", [0, 6, 11, 12])  # 6 / 11 = batch kernels (four-wide / box-pair tree), 12 = packet kernel
 def test_axis_parallel_rays_take_the_exact_path(fixture, kernel, request):
     sc = request.getfixturevalue(fixture)
     pt, df = _irregular_rays(100000, seed=31)
