@@ -67,3 +67,27 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert r["world_size"] == 2 and r["ranks_seen"] == 2 and len(r["device_per_rank"]) == 2
     assert r["distinct_devices"] == 1 and "rehearsal" in r["note"]  # one GPU here; 8 distinct bus ids on the node
     assert r["gather_ms"] > 0
+
+
+def test_the_rccl_path_of_the_bench_on_a_world_of_one_rank():
+    """What an 8-GPU node runs, as far as one GPU can: backend nccl (RCCL) for the process group, the library's own
+    communicator from a unique id that torch.distributed hands round, and the gather through the C ABI
+    (nova_hip_tiles_allgather) inside the timed region — with a world of ONE rank under the launcher
+    (NOVA_BENCH_FORCE_DIST=1).  FXAA on, so the float4 means travel and the frame is post-processed after the gather."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k != "NOVA_BENCH_BACKEND"}
+    env.update(NOVA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "448", "--height", "256", "--check-frame",
+           "--anti-aliasing"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["frame_check"] is True and out["scaling"] == "strong"
+    r = out["rccl"]
+    assert r["backend"].startswith("nccl") and r["gather"].startswith("nova_hip_tiles_allgather")
+    assert r["library_comm_ranks"] == [1] and r["rccl_version"] > 0 and r["distinct_devices"] == 1
