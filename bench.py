@@ -319,9 +319,12 @@ def other_configs(capi, S, Raytracer, rates, which):
                 "frac_of_measured_copy": round(achieved / rates["hbm_copy_gbs"], 4),
                 "working_set_bytes": int(n_nodes) * 32 + n_tri * 48, "traffic": None}
         counters_view(roof, load_pmc("pmc_traffic_c4.json"), launch_s, n, rates, "pmc_traffic_c4.json")
-        if roof["frac"] > 1.0:
-            roof["frac_note"] = ("requested bytes per second over the HBM peak: above 1 because the binned rays share lines in L2 "
-                                 "(what HBM really moved: traffic / hbm_frac_counter)")
+        # For this block `frac` is what HBM really moved (the counters) over the peak: the requested bytes per second
+        # exceed the HBM peak once the binned rays share lines in L2, and a fraction above 1 says nothing.
+        roof["requested_frac"] = roof["frac"]
+        if roof.get("hbm_frac_counter") is not None:
+            roof["frac"] = roof["hbm_frac_counter"]
+            roof["frac_how"] = "HBM bytes per launch by the counters (traffic) / launch time / peak; requested_frac = walked bytes instead"
         out["c4"] = {"workload": f"{n_tri}-triangle soup (seed 4; BVH {n_nodes} nodes built on the device in {stats['device_ms']:.1f} ms), "
                                  f"{n} uniform random closest-hit rays per batch (seed 5)",
                      "ms_per_batch": round(dt * 1e3, 3), "mrays_per_s": round(n / dt / 1e6, 1),

@@ -31,7 +31,7 @@ valu_pipe_busy = round(active / (8.0 * busy), 4) if active and busy else None
 wave_cycles, wait_inst = per("SQ_WAVE_CYCLES"), per("SQ_WAIT_INST_ANY")
 json.dump({
     "kernel": kernel, "dispatches": cnt["FETCH_SIZE"],
-    "source": "profiles/" + out.split("/")[-1] + " (rocprofv3 --pmc passes of scripts/pmc_passes.sh)",
+    "source": "profiles/" + out.split("/")[-1] + " (rocprofv3 --pmc passes of scripts/" + ("pmc_c4.sh" if "c4" in out else "pmc_passes.sh") + ")",
     "valu_pipe_busy": valu_pipe_busy,
     "valu_pipe_busy_how": "SQ_ACTIVE_INST_VALU (4-cycle units over all SIMDs) x 4 / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs)",
     "wave_cycles_waiting_frac": round(wait_inst / wave_cycles, 4) if wave_cycles and wait_inst else None,
