@@ -299,7 +299,8 @@ int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* sta
  *   every rank:  nova_hip_tiles_allgather(image)         (pack -> ncclAllGather -> unpack on the library's stream:
  *                                                          afterwards EVERY rank's image holds all ranks' tiles)
  * A caller that already has an ncclComm_t hands it over with nova_hip_tiles_comm_adopt (the library then never
- * destroys it).  librccl is opened on first use, from the directory of the HIP runtime the library is bound to
+ * destroys it; the handle must come from the librccl the library itself uses — nova_hip_comm_info.rccl_path — and
+ * live on the library's device).  librccl is opened on first use, from the directory of the HIP runtime the library is bound to
  * (env NOVA_HIP_RCCL = full path overrides); single-GPU callers never load it.  The send and receive stacks are
  * the library's own buffers, grown on demand.  With anti_aliasing gather temp_color2 (float4), set
  * NOVA_HIP_OPT_TILE_RANKS = 1 on the rank that writes the frame and post-process there; without it post-process
