@@ -381,6 +381,10 @@ enum {
   NOVA_HIP_OPT_ALLOC_CALLS = 10, /* read-only (nova_hip_get_option): allocating HIP runtime calls the library has made so far
                                     (hipMalloc / hipFree / pinned memory / event and stream creation); what
                                     tests/test_zz_no_alloc.py checks nova_hip_trace_rays_noalloc against */
+  NOVA_HIP_OPT_MIS_PRETEST = 11, /* 1 (default): a MIS ray (kernels/raytrace.hpp:234-263) is first tested against the
+                                    triangles that carry a light index; it is traced only if it passes one of them, and
+                                    then no farther than that.  The frame is the reference's bit for bit either way
+                                    (nova_amd/csrc/shade.hpp gives the argument); 0 traces every MIS ray */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };
@@ -389,7 +393,8 @@ int nova_hip_get_option(int option, int64_t* value);
 
 typedef struct {
   uint64_t rays_primary;      /* find_intersection calls for first path segments */
-  uint64_t rays_bounce;       /* closest-hit calls for later segments and MIS rays */
+  uint64_t rays_bounce;       /* closest-hit calls for later segments and MIS rays (every MIS ray of the reference's
+                                 schedule, traced or not: see rays_mis_pretested) */
   uint64_t rays_shadow;       /* any-hit calls */
   uint64_t node_visits;       /* 64-byte node lines fetched (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t triangle_tests;    /* intersects_triangle evaluations (NOVA_HIP_OPT_COUNT_WORK) */
@@ -400,6 +405,8 @@ typedef struct {
   uint64_t traverse_launches;
   double camera_traverse_ms;  /* the part of traverse_ms / traverse_launches spent on camera-ray */
   uint64_t camera_traverse_launches; /* launches (first path segments), which run their own kernel */
+  uint64_t rays_mis_pretested; /* of rays_bounce: MIS rays answered by the light pre-test, no traversal
+                                  (NOVA_HIP_OPT_MIS_PRETEST) */
 } nova_hip_counters;
 int nova_hip_get_counters(nova_hip_counters* out);
 /* Roofline denominators measured on the device the library runs on (no counterpart in the reference;

@@ -19,6 +19,7 @@ OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT
     1, 2, 3, 4, 5, 6, 7, 8
 OPT_CLAMP_TO_EDGE = 9
 OPT_ALLOC_CALLS = 10  # read-only
+OPT_MIS_PRETEST = 11
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 
@@ -60,7 +61,7 @@ class Counters(ctypes.Structure):
                 ("triangle_tests", ctypes.c_uint64), ("path_segments", ctypes.c_uint64),
                 ("traverse_ms", ctypes.c_double), ("shade_ms", ctypes.c_double),
                 ("traverse_launches", ctypes.c_uint64), ("camera_traverse_ms", ctypes.c_double),
-                ("camera_traverse_launches", ctypes.c_uint64)]
+                ("camera_traverse_launches", ctypes.c_uint64), ("rays_mis_pretested", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -21,16 +21,18 @@ namespace nova_hip {
 
 NOVA_ARG_LAYOUT(ImageView, 48, 8);
 NOVA_ARG_LAYOUT(PathPlanes, 48, 8);
-NOVA_ARG_LAYOUT(FrameArgs, 328, 8);
-NOVA_ARG_LAYOUT(TraverseArgs, 152, 8);
+NOVA_ARG_LAYOUT(FrameArgs, 344, 8);
+NOVA_ARG_LAYOUT(TraverseArgs, 160, 8);
 NOVA_ARG_LAYOUT(AccumulateArgs, 104, 8);
 NOVA_ARG_LAYOUT(PostArgs, 80, 8);
 NOVA_ARG_LAYOUT(LeafRec, 32, 4);
 static_assert(offsetof(ImageView, u8) == 24 && offsetof(ImageView, lut) == 32 && offsetof(ImageView, edge) == 40,
               "ImageView members");
-static_assert(offsetof(FrameArgs, materials) == 176 && offsetof(FrameArgs, sky) == 224 && offsetof(FrameArgs, out_color) == 280,
+static_assert(offsetof(FrameArgs, materials) == 176 && offsetof(FrameArgs, sky) == 224 && offsetof(FrameArgs, out_color) == 280 &&
+              offsetof(FrameArgs, n_mis) == 328 && offsetof(FrameArgs, light_tris) == 336,
               "FrameArgs members");
-static_assert(offsetof(TraverseArgs, wide) == 112 && offsetof(TraverseArgs, perm) == 144, "TraverseArgs members");
+static_assert(offsetof(TraverseArgs, wide) == 112 && offsetof(TraverseArgs, perm) == 144 && offsetof(TraverseArgs, n_extra_ptr) == 152,
+              "TraverseArgs members");
 
 #undef NOVA_ARG_LAYOUT
 

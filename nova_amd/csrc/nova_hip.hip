@@ -58,7 +58,8 @@ namespace {
 
 constexpr uint32_t kMaxIterations = 1024; // hard cap on path length in unbounded mode
 constexpr uint32_t kTileSize = 64;
-constexpr size_t kQueueWords = 2048; // >= kMaxIterations + 2 path counters, a multiple of the head stride
+constexpr size_t kQueueWords = 4096; // path counters [0, kMaxIterations + 2), MIS-ray counters from kMisWords on; a multiple of the head stride
+constexpr size_t kMisWords = 2048;
 
 #define HIP_TRY(expr)                        \
   do {                                       \
@@ -92,7 +93,7 @@ struct FrameBuffers {
   float4* ray_o[2] = {};
   float4* ray_d[2] = {};
   float4* hits = nullptr;
-  unsigned long long* block_counters = nullptr; // [capacity / kShadeBlock][4]
+  unsigned long long* block_counters = nullptr; // [capacity / kShadeBlock][kBlockCounters]
   uint32_t n_blocks = 0;
 };
 
@@ -162,6 +163,13 @@ struct Ctx {
   uint32_t comm_rank = 0, comm_ranks = 0;
   void* d_gather = nullptr;              // [send stack][ranks receive stacks]
   size_t gather_bytes = 0;
+  // light pre-test of MIS rays (shade.hpp): the triangles of `lt_meta` (at that version) that carry a light index
+  uint32_t* d_light_tris = nullptr;      // kLightTriWords words
+  const void* lt_meta = nullptr;
+  const void* lt_tri_ptr = nullptr;
+  uint64_t lt_version = 0, lt_tri_version = 0;
+  uint32_t lt_tris = 0;
+  int64_t opt_mis_pretest = 1;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -175,7 +183,7 @@ struct Ctx {
   double traverse_ms = 0, camera_ms = 0, shade_ms = 0;
   uint64_t traverse_launches = 0, camera_launches = 0;
   uint64_t host_primary = 0; // primary rays = valid pixels of the tiles rendered
-  uint64_t folded[4] = { 0, 0, 0, 0 }; // block counters of released frame buffers
+  uint64_t folded[kBlockCounters] = {}; // block counters of released frame buffers
   // further lanes of nova_hip_render_samples (made on first use) and what orders the lanes.
   // lanes[cur] is stale: the current lane lives in the fields above (switch_lane).
   Lane lanes[kMaxLanes];
@@ -323,13 +331,13 @@ void free_frame_buffers(FrameBuffers& fb) {
   fb.n_blocks = 0;
 }
 
-// per-block ray counters of a lane's frame buffers, added to bc[4]
-int add_block_counters(const FrameBuffers& fb, uint64_t bc[4]) {
+// per-block ray counters of a lane's frame buffers, added to bc[]
+int add_block_counters(const FrameBuffers& fb, uint64_t bc[kBlockCounters]) {
   if (!fb.block_counters) return 0;
-  std::vector<unsigned long long> hb(4 * static_cast<size_t>(fb.n_blocks));
+  std::vector<unsigned long long> hb(kBlockCounters * static_cast<size_t>(fb.n_blocks));
   HIP_TRY(hipMemcpy(hb.data(), fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost));
   for (size_t b = 0; b < fb.n_blocks; b++)
-    for (int q = 0; q < 4; q++) bc[q] += hb[4 * b + q];
+    for (int q = 0; q < kBlockCounters; q++) bc[q] += hb[kBlockCounters * b + q];
   return 0;
 }
 
@@ -616,10 +624,10 @@ int ensure_frame_buffers(uint32_t paths) {
   };
   // counts accumulated so far live in the old per-block slots: fold them into the totals first
   if (fb.block_counters) {
-    std::vector<unsigned long long> hb(4 * static_cast<size_t>(fb.n_blocks));
+    std::vector<unsigned long long> hb(kBlockCounters * static_cast<size_t>(fb.n_blocks));
     if (hipMemcpy(hb.data(), fb.block_counters, hb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       for (size_t b = 0; b < fb.n_blocks; b++)
-        for (int q = 0; q < 4; q++) g.folded[q] += hb[4 * b + q];
+        for (int q = 0; q < kBlockCounters; q++) g.folded[q] += hb[kBlockCounters * b + q];
     }
   }
   release();
@@ -636,8 +644,8 @@ int ensure_frame_buffers(uint32_t paths) {
   hipError_t e = hipMalloc(&fb.hits, 3 * plane);
   if (e != hipSuccess) { release(); return static_cast<int>(e); }
   fb.n_blocks = (paths + kShadeBlock - 1) / kShadeBlock;
-  e = hipMalloc(&fb.block_counters, 4 * static_cast<size_t>(fb.n_blocks) * 8);
-  if (e == hipSuccess) e = hipMemset(fb.block_counters, 0, 4 * static_cast<size_t>(fb.n_blocks) * 8);
+  e = hipMalloc(&fb.block_counters, kBlockCounters * static_cast<size_t>(fb.n_blocks) * 8);
+  if (e == hipSuccess) e = hipMemset(fb.block_counters, 0, kBlockCounters * static_cast<size_t>(fb.n_blocks) * 8);
   if (e != hipSuccess) { release(); return static_cast<int>(e); }
   fb.capacity = paths;
   return 0;
@@ -850,6 +858,7 @@ int nova_hip_init(int device_ordinal) {
   HIP_TRY(hipMalloc(&g.d_counters, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&g.h_pinned, 64, hipHostMallocDefault));
+  HIP_TRY(hipMalloc(&g.d_light_tris, kLightTriWords * sizeof(uint32_t)));
   g.device = device_ordinal;
   g.ready = true;
   return 0;
@@ -893,6 +902,7 @@ int nova_hip_shutdown(void) {
   (void) hipFree(g.d_spill);
   (void) hipFree(g.d_queues);
   (void) hipFree(g.d_counters);
+  (void) hipFree(g.d_light_tris);
   (void) hipHostFree(g.h_pinned);
   (void) hipStreamDestroy(g.stream);
   for (int l = 1; l < g.lanes_ready; l++) {
@@ -914,14 +924,14 @@ int nova_hip_shutdown(void) {
   // (rays, kernel times) are per context and start again at zero.
   std::unordered_map<const void*, Alloc> allocs = std::move(g.allocs);
   const uint64_t next_version = g.next_version;
-  const int64_t opts[9] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
-                            g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays };
+  const int64_t opts[10] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
+                             g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays, g.opt_mis_pretest };
   g = Ctx {};
   g.allocs = std::move(allocs);
   g.next_version = next_version;
   g.opt_max_depth = opts[0]; g.opt_traversal = opts[1]; g.opt_count_work = opts[2];
   g.opt_tile_rank = opts[3]; g.opt_tile_ranks = opts[4]; g.opt_kernel = opts[5];
-  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8];
+  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8]; g.opt_mis_pretest = opts[9];
   return 0;
 }
 
@@ -1094,6 +1104,9 @@ int nova_hip_set_option(int option, int64_t value) {
     case NOVA_HIP_OPT_CLAMP_TO_EDGE:
       if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_clamp_to_edge = value; return 0;
+    case NOVA_HIP_OPT_MIS_PRETEST:
+      if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_mis_pretest = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1110,6 +1123,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_TUNE: *value = g.opt_tune; return 0;
     case NOVA_HIP_OPT_SORT_RAYS: *value = g.opt_sort_rays; return 0;
     case NOVA_HIP_OPT_CLAMP_TO_EDGE: *value = g.opt_clamp_to_edge; return 0;
+    case NOVA_HIP_OPT_MIS_PRETEST: *value = g.opt_mis_pretest; return 0;
     case NOVA_HIP_OPT_ALLOC_CALLS: *value = static_cast<int64_t>(g_alloc_calls.load()); return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
@@ -1123,7 +1137,8 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   collect_events();
   unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost));
-  uint64_t bc[4] = { g.folded[0], g.folded[1], g.folded[2], g.folded[3] };
+  uint64_t bc[kBlockCounters];
+  for (int q = 0; q < kBlockCounters; q++) bc[q] = g.folded[q];
   rc = add_block_counters(g.fb, bc);
   for (int l = 0; l < g.lanes_ready && rc == 0; l++)
     if (l != g.cur) rc = add_block_counters(g.lanes[l].fb, bc);
@@ -1133,6 +1148,7 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   out->rays_primary = g.host_primary;
   out->rays_bounce = bc[0] + bc[1];
   out->rays_shadow = bc[2];
+  out->rays_mis_pretested = bc[4];
   out->path_segments = bc[3];
   out->traverse_ms = g.traverse_ms;
   out->shade_ms = g.shade_ms;
@@ -1148,10 +1164,10 @@ int nova_hip_reset_counters(void) {
   HIP_TRY(hipStreamSynchronize(g.stream));
   collect_events();
   HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
-  if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, 4 * static_cast<size_t>(g.fb.n_blocks) * 8));
+  if (g.fb.block_counters) HIP_TRY(hipMemset(g.fb.block_counters, 0, kBlockCounters * static_cast<size_t>(g.fb.n_blocks) * 8));
   for (int l = 0; l < g.lanes_ready; l++)
     if (l != g.cur && g.lanes[l].fb.block_counters)
-      HIP_TRY(hipMemset(g.lanes[l].fb.block_counters, 0, 4 * static_cast<size_t>(g.lanes[l].fb.n_blocks) * 8));
+      HIP_TRY(hipMemset(g.lanes[l].fb.block_counters, 0, kBlockCounters * static_cast<size_t>(g.lanes[l].fb.n_blocks) * 8));
   for (auto& f : g.folded) f = 0;
   g.host_primary = 0;
   g.traverse_ms = g.camera_ms = g.shade_ms = 0;
@@ -1170,7 +1186,10 @@ static int enqueue_iteration(const PackedScene& scene, const FrameArgs& F, uint3
   T.ray_d = g.fb.ray_d[in];
   T.hits = g.fb.hits;
   T.n_items_ptr = g.d_queues + it;
-  T.kinds = (nee && it > 0) ? 3u : 1u;
+  // bounce iterations: the continuation and shadow rays of every path (kinds 0 and 1), then the MIS rays that k_shade
+  // did not answer itself, compacted into the slots of kind 2
+  T.kinds = (nee && it > 0) ? 2u : 1u;
+  T.n_extra_ptr = (nee && it > 0) ? g.d_queues + kMisWords + it : nullptr;
   T.stride = P;
   T.queue_head = g.d_heads + kHeadWords * it;
   int rc = launch_traverse(scene, T, it == 0);
@@ -1214,6 +1233,27 @@ static int raytrace_finish(Pending& pd) {
       if (rc) return rc;
     }
   }
+  return 0;
+}
+
+// the list of triangles with a light index for k_shade's pre-test, made once per contents of the meta buffer
+static int ensure_light_tris(const nova_triangle_meta* meta, const Alloc* am, const nova_triangle_data* tris, const Alloc* at,
+                             uint32_t n_tris) {
+  if (g.lt_meta == meta && g.lt_version == am->version && g.lt_tri_ptr == tris && g.lt_tri_version == at->version &&
+      g.lt_tris == n_tris)
+    return 0;
+  HIP_TRY(hipDeviceSynchronize()); // kernels of any lane may still read the old list
+  HIP_TRY(hipMemsetAsync(g.d_light_tris, 0, kLightTriWords * sizeof(uint32_t), g.stream));
+  hipLaunchKernelGGL(k_find_light_tris, dim3((n_tris + 255) / 256), dim3(256), 0, g.stream, meta,
+                     reinterpret_cast<const float4*>(tris), n_tris, g.d_light_tris);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  g.chain_tail = nullptr;
+  g.lt_meta = meta;
+  g.lt_version = am->version;
+  g.lt_tri_ptr = tris;
+  g.lt_tri_version = at->version;
+  g.lt_tris = n_tris;
   return 0;
 }
 
@@ -1293,7 +1333,14 @@ static int raytrace_impl(const nova_scene_params* params, uint32_t time, nova_hi
   F.stride = P;
   F.max_depth = static_cast<uint32_t>(g.opt_max_depth);
   F.n_active = g.d_queues;
+  F.n_mis = g.d_queues + kMisWords;
   F.block_counters = g.fb.block_counters;
+  F.light_tris = nullptr;
+  if (g.opt_mis_pretest && params->path_tracing != 0 && num_lights > 0) {
+    rc = ensure_light_tris(tri_meta, am, triangles, find_alloc(triangles), scene->n_tris);
+    if (rc) return rc;
+    F.light_tris = g.d_light_tris;
+  }
   const bool path_tracing = params->path_tracing != 0;
   const bool nee = path_tracing && num_lights > 0;
   uint32_t last_it;

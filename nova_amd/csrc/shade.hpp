@@ -16,6 +16,7 @@
 
 #include "device_math.hpp"
 #include "nova_hip.h"
+#include "traverse.hpp" // woop: the light pre-test of MIS rays is the traversal's own triangle test
 
 namespace nova_hip {
 
@@ -40,13 +41,32 @@ struct PathPlanes {
   float4* c; // throughput before this segment's update .xyz, flags
   float4* d; // light-sample term (already multiplied by n.l) .xyz, MIS n.l
   float4* e; // MIS brdf value .xyz, light index of the shaded triangle
-  float4* f; // MIS brdf pdf .xyz, unused
+  float4* f; // MIS brdf pdf .xyz, slot of the MIS ray among the rays of kind 2 (kFlagHasMis)
 };
 
 constexpr uint32_t kFlagPending = 1u;    // direct lighting of the previous segment to resolve
 constexpr uint32_t kFlagHasShadow = 2u;  // a light sample (shadow ray) was emitted
 constexpr uint32_t kFlagTerminate = 4u;  // path ends after the resolve
+constexpr uint32_t kFlagHasMis = 8u;     // a MIS ray was traced (it survived the light pre-test)
 constexpr uint32_t kEmptyPixel = 0xFFFFFFFFu;
+
+// Light pre-test of MIS rays (k_shade).  The reference traces a closest-hit ray along the BRDF sample and uses the
+// hit only when it is a triangle with a light index other than the shaded triangle's (kernels/raytrace.hpp:234-263).
+// Whatever a walk reaches, a triangle it ACCEPTS also passes `woop` on its own with h.t = FLT_MAX (during a walk the
+// threshold is only ever lower).  With S = the triangles with such a light index that pass on their own:
+//   S empty     -> the closest hit cannot contribute, whatever it is: the ray is not traced;
+//   S not empty -> far = max t over S, and the ray is traced with tmax = nextafter(far).  If the reference's closest
+//                  hit has t <= far the shortened ray returns that very hit (same triangles reached, same order of
+//                  (t, index)); if not, that hit is not in S, contributes nothing, and the shortened ray misses.
+// Either way the frame is the reference's bit for bit (oracle/nova_oracle.cpp restates this as `mis_pretest`; the CPU
+// suite compares its frames with and without).  ~99 % of the MIS rays of the bench scenes go untraced: a third of
+// the closest-hit rays of every bounce.  Scenes with more than kMaxLightTris triangles that carry a light index
+// (large emissive meshes) trace every MIS ray as before.
+constexpr uint32_t kMaxLightTris = 16;
+// the list: word 0 = count (may exceed the cap), then from word 16 on one 16-word record per triangle:
+// {triangle index, light index, -, -, Woop matrix rows x, y, z}
+constexpr uint32_t kLightTriWords = 16 + 16 * kMaxLightTris;
+constexpr int kBlockCounters = 8; // per k_shade block: bounce, MIS, shadow rays, shaded segments, MIS rays not traced
 
 struct FrameArgs {
   nova_scene_params params;
@@ -69,7 +89,9 @@ struct FrameArgs {
   uint32_t stride;    // P: ray slot of kind k for path j is k * stride + j
   uint32_t max_depth; // 0 = unbounded
   uint32_t* n_active; // n_active[it] = paths entering pass `it`
-  unsigned long long* block_counters; // [block][4]: bounce, MIS, shadow rays, shaded segments
+  unsigned long long* block_counters; // [block][kBlockCounters]
+  uint32_t* n_mis;             // n_mis[it] = MIS rays pass `it`'s traversal reads (kind 2, compacted)
+  const uint32_t* light_tris;  // kLightTriWords words (k_find_light_tris), or null: no pre-test
 };
 
 // Paths per work-group of k_shade = paths per compaction atomic.  Measured on the 1080p frame (ms of generate + shade
@@ -303,6 +325,25 @@ NV_DEV bool path_pixel(const FrameArgs& F, uint32_t p, uint32_t& x, uint32_t& y)
   return x < F.width && y < F.height;
 }
 
+// The triangles that carry a light index, for the pre-test: list[0] counts them all, the first kMaxLightTris are kept.
+__global__ __launch_bounds__(256) void k_find_light_tris(const nova_triangle_meta* meta, const float4* tris, uint32_t n_tris,
+                                                         uint32_t* list) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tris) return;
+  const int light = meta[i].light_index;
+  if (light == -1) return;
+  const uint32_t k = atomicAdd(&list[0], 1u);
+  if (k < kMaxLightTris) {
+    uint32_t* rec = list + 16 + 16 * k;
+    rec[0] = i;
+    rec[1] = static_cast<uint32_t>(light);
+    float4* m = reinterpret_cast<float4*>(rec + 4);
+    m[0] = tris[3 * static_cast<size_t>(i)];
+    m[1] = tris[3 * static_cast<size_t>(i) + 1];
+    m[2] = tris[3 * static_cast<size_t>(i) + 2];
+  }
+}
+
 // Stage 1: camera rays.  kernels/kernels.cu:23-27 (seed) and kernels/raytrace.hpp:117-127.
 __global__ __launch_bounds__(256) void k_generate(FrameArgs F, PathPlanes S, float4* ray_o, float4* ray_d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +392,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
   V3 color { 0.f, 0.f, 0.f }, thr { 1.f, 1.f, 1.f }, thr_before { 0.f, 0.f, 0.f };
   V3 nee_term { 0.f, 0.f, 0.f }, mis_f { 0.f, 0.f, 0.f }, mis_pdf { 0.f, 0.f, 0.f };
   V3 point { 0.f, 0.f, 0.f }, shadow_dir { 0.f, 0.f, 0.f }, mis_dir { 0.f, 0.f, 0.f }, cont_dir { 0.f, 0.f, 0.f };
-  float shadow_tmax = -1.0f, mis_ndl = 0.0f;
+  float shadow_tmax = -1.0f, mis_ndl = 0.0f, mis_tmax = -1.0f;
   int here_light = -1;
   uint32_t rng = 0, pixel = kEmptyPixel, out_flags = 0;
 
@@ -374,7 +415,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
           const float4 sh = hits[static_cast<size_t>(P) + j];
           if (__float_as_int(sh.w) < 0) dc = xyz(sd);
         }
-        const float4 mh = hits[2 * static_cast<size_t>(P) + j];
+        const size_t mis_slot = 2 * static_cast<size_t>(P) + __float_as_uint(sf.w);
+        float4 mh = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (flags & kFlagHasMis) mh = hits[mis_slot];
         const int mis_tri = __float_as_int(mh.w);
         if (mis_tri >= 0) {
           const nova_triangle_meta& lm = F.meta[mis_tri];
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
             const nova_area_light& L = F.lights[lm.light_index];
             const V3 ln = light_normal(L);
             const float la = light_area(L);
-            const V3 ldir = xyz(ray_d_in[2 * static_cast<size_t>(P) + j]);
+            const V3 ldir = xyz(ray_d_in[mis_slot]);
             const float lpdf = mh.x * mh.x / nz(__builtin_fabsf(dot(ln, ldir)) * la);
             const V3 f = xyz(se), bpdf = xyz(sf);
             const V3 w = power_heuristic(bpdf, splat(lpdf));
@@ -475,6 +518,24 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
               mis_pdf = b.pdf();
               mis_ndl = max_(dot(normal, mis_dir), 0.0f);
               emit_mis = true;
+              mis_tmax = kFltMax;
+              if (F.light_tris) { // uniform; the list and the matrices come through the scalar cache
+                const uint32_t n_lt = F.light_tris[0];
+                if (n_lt <= kMaxLightTris) {
+                  RayState lr;
+                  lr.d = mis_dir;
+                  lr.o = fma3(mis_dir, kRayEpsilon, point); // ray_setup
+                  float far = -1.0f;
+                  for (uint32_t k = 0; k < n_lt; k++) {
+                    const uint32_t* rec = F.light_tris + 16 + 16 * k;
+                    if (static_cast<int>(rec[1]) == here_light) continue;
+                    const float4* mx = reinterpret_cast<const float4*>(rec + 4);
+                    HitState lh { kFltMax, 0.0f, 0.0f, -1 };
+                    if (woop(lr, lh, static_cast<int>(rec[0]), mx[0], mx[1], mx[2])) far = max_(far, lh.t);
+                  }
+                  mis_tmax = far < 0.0f ? -1.0f : __uint_as_float(__float_as_uint(max_(far, 1e-30f)) + 1u);
+                }
+              }
             }
             thr_before = thr;
 
@@ -499,7 +560,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
             }
             emit_cont = cont;
             if (emit_shadow || emit_mis) {
-              out_flags = kFlagPending | (emit_shadow ? kFlagHasShadow : 0u) | (cont ? 0u : kFlagTerminate);
+              out_flags = kFlagPending | (emit_shadow ? kFlagHasShadow : 0u) | (cont ? 0u : kFlagTerminate) |
+                          (mis_tmax >= 0.0f ? kFlagHasMis : 0u);
               alive = true;
             } else if (cont) {
               out_flags = 0u;
@@ -518,50 +580,61 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
   // wave would cost more than the shading itself); ray/segment counts go to per-block slots
   // with plain stores, summed on the host when counters are read.
   __shared__ uint32_t s_alive[kShadeBlock / 64];
-  __shared__ uint32_t s_count[4][kShadeBlock / 64];
-  __shared__ uint32_t s_base;
+  __shared__ uint32_t s_count[5][kShadeBlock / 64]; // [4] = MIS rays that are traced
+  __shared__ uint32_t s_base, s_base_mis;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const bool mis_live = alive && emit_mis && mis_tmax >= 0.0f;
   const uint64_t mask = __ballot(alive);
   const uint64_t m_cont = __ballot(alive && emit_cont), m_mis = __ballot(alive && emit_mis),
-                 m_shadow = __ballot(alive && emit_shadow), m_shaded = __ballot(shaded);
+                 m_shadow = __ballot(alive && emit_shadow), m_shaded = __ballot(shaded), m_live = __ballot(mis_live);
   if (lane == 0) {
     s_alive[wave] = static_cast<uint32_t>(__popcll(mask));
     s_count[0][wave] = static_cast<uint32_t>(__popcll(m_cont));
     s_count[1][wave] = static_cast<uint32_t>(__popcll(m_mis));
     s_count[2][wave] = static_cast<uint32_t>(__popcll(m_shadow));
     s_count[3][wave] = static_cast<uint32_t>(__popcll(m_shaded));
+    s_count[4][wave] = static_cast<uint32_t>(__popcll(m_live));
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t total = 0, c[4] = { 0, 0, 0, 0 };
+    uint32_t total = 0, c[5] = { 0, 0, 0, 0, 0 };
     for (uint32_t w = 0; w < kShadeBlock / 64; w++) {
       total += s_alive[w];
-      for (int q = 0; q < 4; q++) c[q] += s_count[q][w];
+      for (int q = 0; q < 5; q++) c[q] += s_count[q][w];
     }
     s_base = total ? atomicAdd(&F.n_active[it + 1], total) : 0u;
-    unsigned long long* bc = F.block_counters + 4 * static_cast<size_t>(blockIdx.x);
+    s_base_mis = c[4] ? atomicAdd(&F.n_mis[it + 1], c[4]) : 0u;
+    unsigned long long* bc = F.block_counters + kBlockCounters * static_cast<size_t>(blockIdx.x);
     for (int q = 0; q < 4; q++)
       if (c[q]) bc[q] += c[q];
+    if (c[1] != c[4]) bc[4] += c[1] - c[4];
   }
   __syncthreads();
   if (alive) {
     uint32_t s = s_base + rank_in_mask(mask);
-    for (uint32_t w = 0; w < wave; w++) s += s_alive[w];
+    uint32_t ms = s_base_mis + rank_in_mask(m_live);
+    for (uint32_t w = 0; w < wave; w++) {
+      s += s_alive[w];
+      ms += s_count[4][w];
+    }
     O.a[s] = make_float4(color.x, color.y, color.z, __uint_as_float(rng));
     O.b[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
     O.c[s] = make_float4(thr_before.x, thr_before.y, thr_before.z, __uint_as_float(out_flags));
     if (out_flags & kFlagPending) {
       O.d[s] = make_float4(nee_term.x, nee_term.y, nee_term.z, mis_ndl);
       O.e[s] = make_float4(mis_f.x, mis_f.y, mis_f.z, __int_as_float(here_light));
-      O.f[s] = make_float4(mis_pdf.x, mis_pdf.y, mis_pdf.z, 0.0f);
+      O.f[s] = make_float4(mis_pdf.x, mis_pdf.y, mis_pdf.z, __uint_as_float(ms));
     }
     ray_o_out[s] = make_float4(point.x, point.y, point.z, emit_cont ? kFltMax : -1.0f);
     ray_d_out[s] = make_float4(cont_dir.x, cont_dir.y, cont_dir.z, __uint_as_float(0u));
     if (F.num_lights > 0) {
-      const size_t s1 = static_cast<size_t>(P) + s, s2 = 2 * static_cast<size_t>(P) + s;
+      const size_t s1 = static_cast<size_t>(P) + s;
       ray_o_out[s1] = make_float4(point.x, point.y, point.z, emit_shadow ? shadow_tmax : -1.0f);
       ray_d_out[s1] = make_float4(shadow_dir.x, shadow_dir.y, shadow_dir.z, __uint_as_float(1u));
-      ray_o_out[s2] = make_float4(point.x, point.y, point.z, emit_mis ? kFltMax : -1.0f);
+    }
+    if (mis_live) {
+      const size_t s2 = 2 * static_cast<size_t>(P) + ms;
+      ray_o_out[s2] = make_float4(point.x, point.y, point.z, mis_tmax);
       ray_d_out[s2] = make_float4(mis_dir.x, mis_dir.y, mis_dir.z, __uint_as_float(0u));
     }
   }

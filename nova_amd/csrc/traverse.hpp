@@ -93,7 +93,26 @@ struct TraverseArgs {
   uint32_t flags;                    // bits 0-1 = RayQueue mode, bit 2 = ray kinds interleaved
   const uint32_t* perm;              // k_traverse_p: queue position w takes ray perm[w] (rays binned by origin cell and
                                      // direction octant, k_ray_keys), or null
+  const uint32_t* n_extra_ptr;       // further work items after the n_items * kinds ones: *n_extra_ptr rays in slots
+                                     // kinds * stride + i (the MIS rays of a frame that survive k_shade's light
+                                     // pre-test, compacted), or null
 };
+
+// work items of a launch and the ray slot of item w
+NV_DEV uint32_t items_total(const TraverseArgs& A, uint32_t n) {
+  return n * A.kinds + (A.n_extra_ptr ? *A.n_extra_ptr : 0u); // the host guarantees n * (kinds + 1) < 2^31
+}
+NV_DEV size_t item_slot(const TraverseArgs& A, uint32_t n, uint32_t w, bool interleave) {
+  const uint32_t main_items = n * A.kinds;
+  if (w >= main_items) return static_cast<size_t>(A.kinds) * A.stride + (w - main_items);
+  uint32_t kind = w / n;
+  uint32_t j = w - kind * n;
+  if (interleave) { // the rays of one path next to each other
+    j = w / A.kinds;
+    kind = w - j * A.kinds;
+  }
+  return static_cast<size_t>(kind) * A.stride + j;
+}
 
 // ---- ray binning for incoherent batches -------------------------------------------------------------
 // A batch of random rays over a scene that does not fit the caches (BASELINE config 4: 0.6 GB of nodes and
@@ -586,7 +605,7 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
   st.stride = gridDim.x * blockDim.x;
   st.spill = A.spill + (blockIdx.x * blockDim.x + threadIdx.x);
   const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  const uint32_t total = items_total(A, n);
   uint32_t n_nodes = 0, n_tris = 0;
 
   RayQueue Q;
@@ -598,9 +617,7 @@ __global__ __launch_bounds__(256) void k_traverse4(TraverseArgs A) {
     const uint32_t w_end = Q.w_end;
     Q.w_next = Q.w_end;
     if (w < w_end) {
-      const uint32_t kind = w / n;
-      const uint32_t j = w - kind * n;
-      const size_t slot = static_cast<size_t>(kind) * A.stride + j;
+      const size_t slot = item_slot(A, n, w, false);
       const float4 o4 = A.ray_o[slot];
       const float4 d4 = A.ray_d[slot];
       HitState h { o4.w, 0.0f, 0.0f, -1 };
@@ -684,7 +701,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
   st.stride = gridDim.x * blockDim.x;
   st.spill = A.spill + (blockIdx.x * blockDim.x + threadIdx.x);
   const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  const uint32_t total = items_total(A, n);
   uint32_t n_nodes = 0, n_tris = 0;
   const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
@@ -718,13 +735,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_traverse_p(TraverseArgs A) {
         const uint32_t my_rank = rank_in_mask(idle);
         if (cur == kDone && my_rank < take) {
           const uint32_t w = Q.w_next + my_rank;
-          uint32_t kind = w / n;
-          uint32_t j = w - kind * n;
-          if (interleave) { // the rays of one path next to each other
-            j = w / A.kinds;
-            kind = w - j * A.kinds;
-          }
-          slot = static_cast<size_t>(kind) * A.stride + j;
+          slot = item_slot(A, n, w, interleave);
           if (A.perm) slot = A.perm[w];
           const float4 o4 = A.ray_o[slot];
           const float4 d4 = A.ray_d[slot];
@@ -1106,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t (*stk)[4] = pstack[threadIdx.x >> 6];
   const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds;
+  const uint32_t total = items_total(A, n);
   uint32_t n_nodes = 0, n_tris = 0;
   const float4 rt = { A.root_top[0], A.root_top[1], A.root_top[2], 0.0f };
   const float4 rb = { A.root_bot[0], A.root_bot[1], A.root_bot[2], 0.0f };
@@ -1125,9 +1136,7 @@ __global__ __launch_bounds__(256) void k_traverse_packet(TraverseArgs A, const N
     bool alive = false, anyhit = false;
     float slack_scale = 0.0f, far_limit = 0.0f;
     if (valid) {
-      const uint32_t kind = w / n;
-      const uint32_t j = w - kind * n;
-      slot = static_cast<size_t>(kind) * A.stride + j;
+      slot = item_slot(A, n, w, false);
       const float4 o4 = A.ray_o[slot];
       const float4 d4 = A.ray_d[slot];
       h.t = o4.w;
@@ -1240,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraverseArgs A) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t (*stk)[64] = lds_stack[threadIdx.x >> 6];
   const uint32_t n = A.n_items_ptr ? *A.n_items_ptr : A.n_items_imm;
-  const uint32_t total = n * A.kinds; // the host guarantees n * kinds < 2^31
+  const uint32_t total = items_total(A, n);
   uint32_t n_nodes = 0, n_tris = 0;
 
   RayQueue Q;
@@ -1252,9 +1261,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraverseArgs A) {
     const uint32_t w_end = Q.w_end;
     Q.w_next = Q.w_end;
     if (w < w_end) {
-      const uint32_t kind = w / n;
-      const uint32_t j = w - kind * n;
-      const size_t slot = static_cast<size_t>(kind) * A.stride + j;
+      const size_t slot = item_slot(A, n, w, false);
       const float4 o4 = A.ray_o[slot];
       const float4 d4 = A.ray_d[slot];
       HitState h { o4.w, 0.0f, 0.0f, -1 };

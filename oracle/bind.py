@@ -31,6 +31,7 @@ def lib() -> ctypes.CDLL:
                                                              ctypes.c_void_p, ctypes.c_void_p]
         _lib.oracle_set_threads.argtypes = [ctypes.c_int]
         _lib.oracle_set_clamp_to_edge.argtypes = [ctypes.c_int]
+        _lib.oracle_set_mis_pretest.argtypes = [ctypes.c_uint32]
     return _lib
 
 
@@ -48,10 +49,14 @@ def set_clamp_to_edge(on: bool):
 
 
 def kernel_raytrace(scene, params, time, width, height, denoise_available=0, meta=None, sky=None,
-                    max_depth=0, ordered=False, count_work=False, rows=None, bands=None, counters=None):
+                    max_depth=0, ordered=False, count_work=False, rows=None, bands=None, counters=None,
+                    mis_pretest=False):
     """kernels/kernels.cu:9-40.  Returns (color, albedo, normal) float32[h, w, 4]; `counters`
-    (uint64[8], optional) accumulates primary/bounce/shadow rays, segments, node visits, tri tests."""
+    (uint64[8], optional) accumulates primary/bounce/shadow rays, segments, node visits, tri tests and — with
+    `mis_pretest` (libnova_hip's light pre-test of MIS rays, not in the reference: nova_oracle.cpp mis_pretest) —
+    the MIS rays not traced / traced with a shortened length."""
     meta = scene.meta if meta is None else meta
+    lib().oracle_set_mis_pretest(int(meta.shape[0]) if mis_pretest else 0)
     sky = scene.sky if sky is None else sky
     color = np.zeros((height, width, 4), np.float32)
     albedo = np.zeros((height, width, 4), np.float32)
@@ -70,6 +75,7 @@ def kernel_raytrace(scene, params, time, width, height, denoise_available=0, met
         ctypes.c_uint32(max_depth), ctypes.c_int(1 if ordered else 0),
         ctypes.c_int(1 if count_work else 0), ctypes.c_uint32(r0), ctypes.c_uint32(r1),
         ctypes.c_uint32(band_rows), ctypes.c_uint32(band_period), _p(counters))
+    lib().oracle_set_mis_pretest(0)
     assert rc == 0
     return color, albedo, normal
 

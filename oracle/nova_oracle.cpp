@@ -537,12 +537,39 @@ struct SceneView {
   const nova_area_light* lights;
   uint32_t num_lights;
   Image materials, sky;
+  // light pre-test of MIS rays (oracle_set_mis_pretest): the triangles that carry a light index, or null
+  const std::vector<std::pair<uint32_t, int>>* light_tris = nullptr;
 };
 
 struct RayCount {
   uint64_t primary = 0, bounce = 0, shadow = 0, segments = 0;
+  uint64_t mis_pretested = 0, mis_shortened = 0;
   WorkCount work;
 };
+
+// Light pre-test of a MIS ray — NOT in the reference; the restatement of what libnova_hip's k_shade does, kept here
+// so that (a) CPU tests can show the frame does not change by a bit and (b) the per-ray work of the rays that are
+// still traversed can be counted.  The MIS ray's closest hit matters only when it is a triangle with a light index
+// other than the shaded triangle's (kernels/raytrace.hpp:247-262).  Whatever the walk reaches, a triangle it ACCEPTS
+// passes intersects_triangle on its own with length = FLT_MAX (the walk's threshold is only ever lower).  So with
+// S = the light triangles (light != the shaded one's) that pass on their own:
+//   S empty      -> the closest hit cannot contribute: no find_intersection call at all;
+//   S not empty  -> far = max t over S; the call runs with hit.length = nextafter(far) instead of FLT_MAX.  If the
+//                   reference's closest hit has t <= far, this call returns the very same hit (same triangles reached,
+//                   same order, same ties); if not, that hit is not in S, contributes nothing, and neither does
+//                   whatever this call returns (a miss).
+// Returns false when the ray need not be traced; else sets `length`.
+inline bool mis_pretest(const SceneView& S, const Ray& ray, int shaded_light, float& length) {
+  float far = -1.0f;
+  for (const auto& lt : *S.light_tris) {
+    if (lt.second == shaded_light) continue;
+    Hit h;
+    if (hit_triangle(ray, h, static_cast<int>(lt.first), S.tris[lt.first], false)) far = fmaxf(far, h.length);
+  }
+  if (far < 0.0f) return false;
+  length = nextafterf(fmaxf(far, 1e-30f), FLT_MAX);
+  return true;
+}
 
 // kernels/raytrace.hpp:104-298.  max_depth = 0 reproduces the reference (unbounded); max_depth
 // = d stops a path after it has shaded (incl. direct lighting) its d-th segment.
@@ -634,7 +661,12 @@ f3 trace_ray(uint32_t& rng, const nova_scene_params& P, int px, int py, const Sc
         Ray mis(point, ldir, kRayEpsilon);
         Hit mh;
         rc.bounce++;
-        if (find(S.tris, S.bvh, mis, mh, false, wc)) {
+        bool traced = true;
+        if (S.light_tris) {
+          traced = mis_pretest(S, mis, m.light_index, mh.length);
+          (traced ? rc.mis_shortened : rc.mis_pretested)++;
+        }
+        if (traced && find(S.tris, S.bvh, mis, mh, false, wc)) {
           const nova_triangle_meta& lm = S.meta[mh.tri];
           if (lm.light_index != -1 && lm.light_index != m.light_index) {
             const nova_area_light& L = S.lights[lm.light_index];
@@ -748,6 +780,7 @@ f3 fxaa(const Image& im, float inv_w, float inv_h, float u, float v) {
 }
 
 int g_threads = 0;
+uint32_t g_mis_pretest_tris = 0; // oracle_set_mis_pretest: number of triangles (0 = off, the reference's schedule)
 
 }
 
@@ -755,6 +788,9 @@ extern "C" {
 
 void oracle_set_threads(int n) { g_threads = n; }
 void oracle_set_clamp_to_edge(int on) { g_clamp_to_edge = on ? 1 : 0; }
+// n_tris > 0: oracle_kernel_raytrace applies the light pre-test to MIS rays (mis_pretest above); counters[6] / [7] =
+// MIS rays not traced / traced with a shortened length.  counters[1] keeps counting every MIS ray.
+void oracle_set_mis_pretest(uint32_t n_tris) { g_mis_pretest_tris = n_tris; }
 
 uint32_t oracle_hash(uint32_t s) { return wang_hash(s); }
 float oracle_rand(uint32_t* st) { return rnd(*st); }
@@ -802,12 +838,18 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
                            uint64_t* counters) {
   SceneView S { tris, meta, bvh, lights, num_lights,
                 { materials, (int) mat_w, (int) mat_h, (int) mat_layers }, { sky, (int) sky_w, (int) sky_h, 1 } };
-  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
   row_end = std::min(row_end, height);
+  std::vector<std::pair<uint32_t, int>> light_tris;
+  if (g_mis_pretest_tris) {
+    for (uint32_t i = 0; i < g_mis_pretest_tris; i++)
+      if (meta[i].light_index != -1) light_tris.push_back({ i, meta[i].light_index });
+    S.light_tris = &light_tris;
+  }
   Slack slack;
   if (ordered) slack = compute_slack(tris, bvh);
   const Slack* slack_ptr = ordered ? &slack : nullptr;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c0, c1, c2, c3, c4, c5) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c0, c1, c2, c3, c4, c5, c6, c7) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
   for (int y = (int) row_begin; y < (int) row_end; y++) {
     RayCount rc;
     // optional row sampling: bands of `band_rows` rows, one band in every `band_period`
@@ -826,10 +868,12 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
     }
     c0 += rc.primary; c1 += rc.bounce; c2 += rc.shadow; c3 += rc.segments;
     c4 += rc.work.nodes; c5 += rc.work.tris;
+    c6 += rc.mis_pretested; c7 += rc.mis_shortened;
   }
   if (counters) {
     counters[0] += c0; counters[1] += c1; counters[2] += c2; counters[3] += c3;
     counters[4] += c4; counters[5] += c5;
+    counters[6] += c6; counters[7] += c7;
   }
   return 0;
 }

@@ -1,6 +1,6 @@
 """One build of the library on the benchmark frame: ms per sample (best of 3 x 16), work counters and a hash of the
 frame bytes.  A/B of two builds: run it once per build with NOVA_HIP_LIB=<path to the .so> and compare the lines."""
-import sys, time, hashlib
+import os, sys, time, hashlib
 sys.path.insert(0, "/root/repo")
 from nova_amd import scene as S, capi
 from nova_amd.raytracer import Raytracer
@@ -12,6 +12,8 @@ p = S.make_scene_params(S.Camera(width=W, height=H, **S.DRAGON_CAMERA), shading_
 rt = Raytracer(0)
 rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
+if os.environ.get("NOVA_AB_MIS_PRETEST") is not None and hasattr(capi, "OPT_MIS_PRETEST"):
+    capi.set_option(capi.OPT_MIS_PRETEST, int(os.environ["NOVA_AB_MIS_PRETEST"]))
 if len(sys.argv) > 1:
     capi.set_option(capi.OPT_TRAVERSE_KERNEL, int(sys.argv[1]))
 rt.start()
@@ -35,6 +37,6 @@ rt.start()
 rt.raytrace(1, read_back=False)
 capi.synchronize()
 w = capi.counters()
-print("%s: %.4f ms per sample, traverse %.4f ms (camera rays %.4f), shade %.4f ms, node lines %d, triangle tests %d, frame sha %s" % (
+print("%s: %.4f ms per sample, traverse %.4f ms (camera rays %.4f), shade %.4f ms, node lines %d, triangle tests %d, frame sha %s, MIS rays not traced %d of %d bounce+MIS rays" % (
     capi.LIB_PATH.split("/")[-1], best * 1e3, k["traverse_ms"] / 16, k["camera_traverse_ms"] / 16, k["shade_ms"] / 16, w["node_visits"], w["triangle_tests"],
-    hashlib.sha256(img.tobytes()).hexdigest()[:16]))
+    hashlib.sha256(img.tobytes()).hexdigest()[:16], w.get("rays_mis_pretested", 0), w["rays_bounce"]))
