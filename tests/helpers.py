@@ -28,3 +28,13 @@ def check_scene(sc, g):
 def id_inputs(sc):
     """meta / sky that make kernel_raytrace (path_tracing = 0) report primary-hit triangle ids."""
     return S.encode_ids_in_kd(sc.meta), S.constant_sky((-1, -1, -1), w=sc.sky.shape[1], h=sc.sky.shape[0])
+
+
+def lit_soup(n_tris=4000, n_emissive=6, seed=11, edge=0.25):
+    """Random triangles in [-1, 1]^3 of which a few large ones emit: lights in the middle of the clutter, so that
+    BRDF samples reach them from everywhere and other triangles often sit in between."""
+    verts = S.soup(n_tris, seed=seed, edge=edge)
+    em = np.zeros((n_tris, 3), np.float32)
+    rng = np.random.default_rng(seed + 1)
+    em[rng.choice(n_tris, n_emissive, replace=False)] = (40.0, 30.0, 20.0)
+    return S.build_scene(verts, emissive=em)
