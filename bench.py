@@ -107,11 +107,12 @@ def cpu_baseline_and_work(oracle, sc, params, width, height, time_seed):
         oracle.kernel_raytrace(sc, params, time_seed + s, width, height, max_depth=MAX_DEPTH, counters=cnt)
     dt = time.perf_counter() - t0
     rays = int(cnt[0] + cnt[1] + cnt[2])
-    # (the rays the library traverses: MIS rays that its light pre-test answers are neither walked nor counted)
+    # (the rays the library traverses: MIS rays that its light pre-test answers and shadow rays of zero light-sample
+    # terms are neither walked nor counted)
     work = np.zeros(8, np.uint64)
     oracle.kernel_raytrace(sc, params, time_seed, width, height, max_depth=MAX_DEPTH,
                            ordered=True, count_work=True, counters=work, mis_pretest=True)
-    wr = int(work[0] + work[1] + work[2]) - int(work[6])
+    wr = int(work[0] + work[1] + work[2]) - int(work[6]) - int(work[7])
     # the camera rays alone (they run in their own kernel): the same frame without path tracing
     cam = np.zeros(8, np.uint64)
     p_cam = np.array(params, copy=True)
@@ -130,6 +131,11 @@ def cpu_baseline_and_work(oracle, sc, params, width, height, time_seed):
                   "(kernels/raytrace.hpp:38-102), OpenMP",
     }
     return base, n_node, n_tri, n_node_cam, n_tri_cam
+
+
+def not_traced(c):
+    """find_intersection calls of the reference's schedule that the library answers without a BVH walk."""
+    return c["rays_mis_pretested"] + c["rays_shadow_skipped"]
 
 
 def walked_work(capi, rt, params, seed):
@@ -151,7 +157,7 @@ def walked_work(capi, rt, params, seed):
         rt.params = keep
     finally:
         capi.set_option(capi.OPT_COUNT_WORK, 0)
-    rays = full["rays_bounce"] + full["rays_shadow"] - full["rays_mis_pretested"]
+    rays = full["rays_bounce"] + full["rays_shadow"] - not_traced(full)
     if rays == 0:
         return None
     lines = (full["node_visits"] - cam["node_visits"]) / rays
@@ -228,7 +234,7 @@ def frame_config(capi, rt, depth, n, label):
     capi.synchronize()
     dt = (time.perf_counter() - t) / n
     c = capi.counters()
-    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c["rays_mis_pretested"]) / n  # traversed
+    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - not_traced(c)) / n  # traversed
     m = max(n, 6)
     rt.start()
     rt.raytrace_samples([2 + i for i in range(m)], read_back=False)
@@ -491,8 +497,8 @@ def main():
     k = capi.counters()
     # rays = rays TRAVERSED.  MIS rays that k_shade's light pre-test answered (NOVA_HIP_OPT_MIS_PRETEST; find_intersection
     # calls of the reference's schedule that the library proves cannot contribute) are reported apart, never in `value`.
-    local = np.array([k["rays_primary"], k["rays_bounce"] - k["rays_mis_pretested"], k["rays_shadow"], k["traverse_launches"],
-                      k["rays_mis_pretested"]], np.float64)
+    local = np.array([k["rays_primary"], k["rays_bounce"] - k["rays_mis_pretested"], k["rays_shadow"] - k["rays_shadow_skipped"],
+                      k["traverse_launches"], k["rays_mis_pretested"], k["rays_shadow_skipped"]], np.float64)
     trav_ms = k["traverse_ms"]
     shade_ms = k["shade_ms"]
     if dist is not None:
@@ -506,7 +512,8 @@ def main():
     else:
         total = local
     rays_primary, rays_bounce, rays_shadow = (int(x) for x in total[:3])
-    rays_pretested = int(total[4])
+    rays_pretested, rays_dark = int(total[4]), int(total[5])
+    rays_untraced = rays_pretested + rays_dark
     rays = rays_primary + rays_bounce + rays_shadow
     rays_local = int(local[0] + local[1] + local[2])
 
@@ -593,12 +600,14 @@ def main():
             },
             "rays_per_step": rays // args.steps,
             "ray_count": "rays traversed (1 ray = 1 BVH walk).  The reference's schedule has "
-                         f"{(rays + rays_pretested) // args.steps} find_intersection calls per step; {rays_pretested // args.steps} of them "
-                         "are MIS rays that k_shade's light pre-test answers without a walk (frame bit-identical, "
-                         "NOVA_HIP_OPT_MIS_PRETEST) and are NOT counted in `value`",
-            "rays_per_step_reference_schedule": (rays + rays_pretested) // args.steps,
+                         f"{(rays + rays_untraced) // args.steps} find_intersection calls per step; {rays_pretested // args.steps} of them "
+                         f"are MIS rays that k_shade's light pre-test answers without a walk and {rays_dark // args.steps} shadow rays "
+                         "of light samples whose term is +0 (frame bit-identical either way, NOVA_HIP_OPT_MIS_PRETEST): "
+                         "those are NOT counted in `value`",
+            "rays_per_step_reference_schedule": (rays + rays_untraced) // args.steps,
             "mis_rays_pretested_per_step": rays_pretested // args.steps,
-            "mrays_per_s_reference_schedule": round((rays + rays_pretested) / dt / 1e6, 2),
+            "shadow_rays_skipped_per_step": rays_dark // args.steps,
+            "mrays_per_s_reference_schedule": round((rays + rays_untraced) / dt / 1e6, 2),
             "mrays_per_s_primary": round(rays_primary / dt / 1e6, 2),
             "mrays_per_s_incoherent": round((rays_bounce + rays_shadow) / dt / 1e6, 2),
             "mrays_per_s_per_gpu": round(rays / dt / 1e6 / world, 2),
@@ -702,7 +711,7 @@ def main():
             capi.synchronize()
             adt = time.perf_counter() - a0
             ka = capi.counters()
-            arays = ka["rays_primary"] + ka["rays_bounce"] + ka["rays_shadow"] - ka["rays_mis_pretested"]
+            arays = ka["rays_primary"] + ka["rays_bounce"] + ka["rays_shadow"] - not_traced(ka)
             out["same_workload_one_gpu"] = {"ms_per_step": round(adt / args.steps * 1e3, 4),
                                             "value": round(arays / adt / 1e6, 2), "unit": "Mrays/s",
                                             "rays_per_step": int(arays // args.steps)}

@@ -384,7 +384,9 @@ enum {
   NOVA_HIP_OPT_MIS_PRETEST = 11, /* 1 (default): a MIS ray (kernels/raytrace.hpp:234-263) is first tested against the
                                     triangles that carry a light index; it is traced only if it passes one of them, and
                                     then no farther than that.  The frame is the reference's bit for bit either way
-                                    (nova_amd/csrc/shade.hpp gives the argument); 0 traces every MIS ray */
+                                    (nova_amd/csrc/shade.hpp gives the argument).  Likewise the shadow ray of a light
+                                    sample whose term is +0 in every channel (light below the surface's horizon) is
+                                    not traced: blocked or not, the same +0 is added.  0 traces every ray */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };
@@ -395,7 +397,7 @@ typedef struct {
   uint64_t rays_primary;      /* find_intersection calls for first path segments */
   uint64_t rays_bounce;       /* closest-hit calls for later segments and MIS rays (every MIS ray of the reference's
                                  schedule, traced or not: see rays_mis_pretested) */
-  uint64_t rays_shadow;       /* any-hit calls */
+  uint64_t rays_shadow;       /* any-hit calls (every one of the reference's schedule: see rays_shadow_skipped) */
   uint64_t node_visits;       /* 64-byte node lines fetched (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t triangle_tests;    /* intersects_triangle evaluations (NOVA_HIP_OPT_COUNT_WORK) */
   uint64_t path_segments;     /* shaded hits */
@@ -407,6 +409,7 @@ typedef struct {
   uint64_t camera_traverse_launches; /* launches (first path segments), which run their own kernel */
   uint64_t rays_mis_pretested; /* of rays_bounce: MIS rays answered by the light pre-test, no traversal
                                   (NOVA_HIP_OPT_MIS_PRETEST) */
+  uint64_t rays_shadow_skipped; /* of rays_shadow: shadow rays of light samples whose term is +0, not traced */
 } nova_hip_counters;
 int nova_hip_get_counters(nova_hip_counters* out);
 /* Roofline denominators measured on the device the library runs on (no counterpart in the reference;

@@ -61,7 +61,8 @@ class Counters(ctypes.Structure):
                 ("triangle_tests", ctypes.c_uint64), ("path_segments", ctypes.c_uint64),
                 ("traverse_ms", ctypes.c_double), ("shade_ms", ctypes.c_double),
                 ("traverse_launches", ctypes.c_uint64), ("camera_traverse_ms", ctypes.c_double),
-                ("camera_traverse_launches", ctypes.c_uint64), ("rays_mis_pretested", ctypes.c_uint64)]
+                ("camera_traverse_launches", ctypes.c_uint64), ("rays_mis_pretested", ctypes.c_uint64),
+                ("rays_shadow_skipped", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

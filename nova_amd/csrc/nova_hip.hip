@@ -1149,6 +1149,7 @@ int nova_hip_get_counters(nova_hip_counters* out) {
   out->rays_bounce = bc[0] + bc[1];
   out->rays_shadow = bc[2];
   out->rays_mis_pretested = bc[4];
+  out->rays_shadow_skipped = bc[5];
   out->path_segments = bc[3];
   out->traverse_ms = g.traverse_ms;
   out->shade_ms = g.shade_ms;

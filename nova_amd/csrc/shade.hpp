@@ -66,7 +66,7 @@ constexpr uint32_t kMaxLightTris = 16;
 // the list: word 0 = count (may exceed the cap), then from word 16 on one 16-word record per triangle:
 // {triangle index, light index, -, -, Woop matrix rows x, y, z}
 constexpr uint32_t kLightTriWords = 16 + 16 * kMaxLightTris;
-constexpr int kBlockCounters = 8; // per k_shade block: bounce, MIS, shadow rays, shaded segments, MIS rays not traced
+constexpr int kBlockCounters = 8; // per k_shade block: bounce, MIS, shadow rays, shaded segments, MIS rays not traced, shadow rays not traced
 
 struct FrameArgs {
   nova_scene_params params;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
     F.materials.lut = s_u8_lut;
   }
   bool alive = false;
-  bool emit_shadow = false, emit_mis = false, emit_cont = false, shaded = false;
+  bool emit_shadow = false, emit_mis = false, emit_cont = false, shaded = false, shadow_live = false;
 
   // values carried to the append step
   V3 color { 0.f, 0.f, 0.f }, thr { 1.f, 1.f, 1.f }, thr_before { 0.f, 0.f, 0.f };
@@ -510,6 +510,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
               const V3 c = (((static_cast<float>(F.num_lights) * w) * v3(L.intensity)) * f) / lpdf;
               nee_term = c * max_(dot(normal, shadow_dir), 0.0f);
               emit_shadow = true;
+              // a term of +0 in every channel (the light is below this surface's horizon: eval() is zero) is what the
+              // resolve adds whether the shadow ray is blocked or not, so that ray is not traced (same option)
+              shadow_live = !(F.light_tris && (__float_as_uint(nee_term.x) | __float_as_uint(nee_term.y) |
+                                               __float_as_uint(nee_term.z)) == 0u);
               // BRDF sample for MIS (raytrace.hpp:234-263); resolved by the next pass
               b.init(out_dir, normal, diffuse, metallic, roughness);
               mis_dir = b.sample(rng);
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
             }
             emit_cont = cont;
             if (emit_shadow || emit_mis) {
-              out_flags = kFlagPending | (emit_shadow ? kFlagHasShadow : 0u) | (cont ? 0u : kFlagTerminate) |
+              out_flags = kFlagPending | (shadow_live ? kFlagHasShadow : 0u) | (cont ? 0u : kFlagTerminate) |
                           (mis_tmax >= 0.0f ? kFlagHasMis : 0u);
               alive = true;
             } else if (cont) {
@@ -580,13 +584,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
   // wave would cost more than the shading itself); ray/segment counts go to per-block slots
   // with plain stores, summed on the host when counters are read.
   __shared__ uint32_t s_alive[kShadeBlock / 64];
-  __shared__ uint32_t s_count[5][kShadeBlock / 64]; // [4] = MIS rays that are traced
+  __shared__ uint32_t s_count[6][kShadeBlock / 64]; // [4] = MIS rays that are traced, [5] = shadow rays that are not
   __shared__ uint32_t s_base, s_base_mis;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const bool mis_live = alive && emit_mis && mis_tmax >= 0.0f;
   const uint64_t mask = __ballot(alive);
   const uint64_t m_cont = __ballot(alive && emit_cont), m_mis = __ballot(alive && emit_mis),
-                 m_shadow = __ballot(alive && emit_shadow), m_shaded = __ballot(shaded), m_live = __ballot(mis_live);
+                 m_shadow = __ballot(alive && emit_shadow), m_shaded = __ballot(shaded), m_live = __ballot(mis_live),
+                 m_dark = __ballot(alive && emit_shadow && !shadow_live);
   if (lane == 0) {
     s_alive[wave] = static_cast<uint32_t>(__popcll(mask));
     s_count[0][wave] = static_cast<uint32_t>(__popcll(m_cont));
@@ -594,13 +599,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
     s_count[2][wave] = static_cast<uint32_t>(__popcll(m_shadow));
     s_count[3][wave] = static_cast<uint32_t>(__popcll(m_shaded));
     s_count[4][wave] = static_cast<uint32_t>(__popcll(m_live));
+    s_count[5][wave] = static_cast<uint32_t>(__popcll(m_dark));
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t total = 0, c[5] = { 0, 0, 0, 0, 0 };
+    uint32_t total = 0, c[6] = { 0, 0, 0, 0, 0, 0 };
     for (uint32_t w = 0; w < kShadeBlock / 64; w++) {
       total += s_alive[w];
-      for (int q = 0; q < 5; q++) c[q] += s_count[q][w];
+      for (int q = 0; q < 6; q++) c[q] += s_count[q][w];
     }
     s_base = total ? atomicAdd(&F.n_active[it + 1], total) : 0u;
     s_base_mis = c[4] ? atomicAdd(&F.n_mis[it + 1], c[4]) : 0u;
@@ -608,6 +614,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
     for (int q = 0; q < 4; q++)
       if (c[q]) bc[q] += c[q];
     if (c[1] != c[4]) bc[4] += c[1] - c[4];
+    if (c[5]) bc[5] += c[5];
   }
   __syncthreads();
   if (alive) {
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(FrameArgs F, uint32_t it,
     ray_d_out[s] = make_float4(cont_dir.x, cont_dir.y, cont_dir.z, __uint_as_float(0u));
     if (F.num_lights > 0) {
       const size_t s1 = static_cast<size_t>(P) + s;
-      ray_o_out[s1] = make_float4(point.x, point.y, point.z, emit_shadow ? shadow_tmax : -1.0f);
+      ray_o_out[s1] = make_float4(point.x, point.y, point.z, shadow_live ? shadow_tmax : -1.0f);
       ray_d_out[s1] = make_float4(shadow_dir.x, shadow_dir.y, shadow_dir.z, __uint_as_float(1u));
     }
     if (mis_live) {

@@ -53,8 +53,8 @@ def kernel_raytrace(scene, params, time, width, height, denoise_available=0, met
                     mis_pretest=False):
     """kernels/kernels.cu:9-40.  Returns (color, albedo, normal) float32[h, w, 4]; `counters`
     (uint64[8], optional) accumulates primary/bounce/shadow rays, segments, node visits, tri tests and — with
-    `mis_pretest` (libnova_hip's light pre-test of MIS rays, not in the reference: nova_oracle.cpp mis_pretest) —
-    the MIS rays not traced / traced with a shortened length."""
+    `mis_pretest` (libnova_hip's two rules for rays whose answer cannot matter, not in the reference: nova_oracle.cpp) —
+    the MIS rays / shadow rays not traced ([6], [7])."""
     meta = scene.meta if meta is None else meta
     lib().oracle_set_mis_pretest(int(meta.shape[0]) if mis_pretest else 0)
     sky = scene.sky if sky is None else sky

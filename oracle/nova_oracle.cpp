@@ -543,7 +543,7 @@ struct SceneView {
 
 struct RayCount {
   uint64_t primary = 0, bounce = 0, shadow = 0, segments = 0;
-  uint64_t mis_pretested = 0, mis_shortened = 0;
+  uint64_t mis_pretested = 0, shadow_skipped = 0;
   WorkCount work;
 };
 
@@ -645,7 +645,23 @@ f3 trace_ray(uint32_t& rng, const nova_scene_params& P, int px, int py, const Sc
         Hit sh;
         sh.length = ldist - kRayEpsilon;
         rc.shadow++;
-        if (!find(S.tris, S.bvh, shadow, sh, true, wc)) {
+        bool traced = true;
+        if (S.light_tris) {
+          // libnova_hip's second rule (not in the reference): the light sample's term is computed before the shadow
+          // ray is traced; when it is +0 in all three channels (the light is below the surface's horizon: eval()
+          // returns zero) the ray's answer cannot change direct_color — it stays +0 either way — and the ray is
+          // not traced
+          Brdf b0(ldir, out_dir, normal, diffuse, metallic, roughness);
+          f3 f0 = b0.eval();
+          float lpdf0 = b0.light_pdf(ln, ldist, la);
+          f3 w0 = power_heuristic(splat(lpdf0), b0.pdf());
+          f3 term = ((((static_cast<float>(S.num_lights) * w0) * v3(L.intensity)) * f0) / lpdf0) * fmaxf(dot(normal, ldir), 0.0f);
+          uint32_t bits[3];
+          std::memcpy(bits, &term, sizeof(bits));
+          traced = (bits[0] | bits[1] | bits[2]) != 0;
+          if (!traced) rc.shadow_skipped++;
+        }
+        if (traced && !find(S.tris, S.bvh, shadow, sh, true, wc)) {
           Brdf b(ldir, out_dir, normal, diffuse, metallic, roughness);
           f3 f = b.eval();
           float lpdf = b.light_pdf(ln, ldist, la);
@@ -664,7 +680,7 @@ f3 trace_ray(uint32_t& rng, const nova_scene_params& P, int px, int py, const Sc
         bool traced = true;
         if (S.light_tris) {
           traced = mis_pretest(S, mis, m.light_index, mh.length);
-          (traced ? rc.mis_shortened : rc.mis_pretested)++;
+          if (!traced) rc.mis_pretested++;
         }
         if (traced && find(S.tris, S.bvh, mis, mh, false, wc)) {
           const nova_triangle_meta& lm = S.meta[mh.tri];
@@ -788,8 +804,9 @@ extern "C" {
 
 void oracle_set_threads(int n) { g_threads = n; }
 void oracle_set_clamp_to_edge(int on) { g_clamp_to_edge = on ? 1 : 0; }
-// n_tris > 0: oracle_kernel_raytrace applies the light pre-test to MIS rays (mis_pretest above); counters[6] / [7] =
-// MIS rays not traced / traced with a shortened length.  counters[1] keeps counting every MIS ray.
+// n_tris > 0: oracle_kernel_raytrace applies libnova_hip's two rules for rays whose answer cannot matter — the light
+// pre-test of MIS rays (mis_pretest above) and the shadow rays of light samples whose term is +0; counters[6] / [7] =
+// MIS rays / shadow rays not traced.  counters[1] and [2] keep counting every ray of the reference's schedule.
 void oracle_set_mis_pretest(uint32_t n_tris) { g_mis_pretest_tris = n_tris; }
 
 uint32_t oracle_hash(uint32_t s) { return wang_hash(s); }
@@ -868,7 +885,7 @@ int oracle_kernel_raytrace(const nova_scene_params* params, uint32_t time, float
     }
     c0 += rc.primary; c1 += rc.bounce; c2 += rc.shadow; c3 += rc.segments;
     c4 += rc.work.nodes; c5 += rc.work.tris;
-    c6 += rc.mis_pretested; c7 += rc.mis_shortened;
+    c6 += rc.mis_pretested; c7 += rc.shadow_skipped;
   }
   if (counters) {
     counters[0] += c0; counters[1] += c1; counters[2] += c2; counters[3] += c3;

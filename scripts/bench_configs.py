@@ -27,7 +27,7 @@ def frames(rt, n, depth, label):
     capi.synchronize()
     dt = (time.perf_counter() - t) / n
     c = capi.counters()
-    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0)) / n
+    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0) - c.get("rays_shadow_skipped", 0)) / n
     print("%s: %.2f ms/frame, %.2f Mrays/frame -> %.0f Mrays/s (traverse %.2f ms, shade %.2f ms per frame)" % (
         label, dt * 1e3, rays / 1e6, rays / dt / 1e6, c["traverse_ms"] / n, c["shade_ms"] / n), flush=True)
     # the same frames through nova_hip_render_samples: n samples per call
@@ -42,7 +42,7 @@ def frames(rt, n, depth, label):
     capi.synchronize()
     fdt = (time.perf_counter() - t) / m
     c = capi.counters()
-    frays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0)) / m
+    frays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0) - c.get("rays_shadow_skipped", 0)) / m
     print("%s, %d samples per call: %.2f ms/sample -> %.0f Mrays/s" % (label, m, fdt * 1e3, frays / fdt / 1e6), flush=True)
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
 

@@ -19,7 +19,7 @@ capi.reset_counters()
 rt.raytrace(2, read_back=False)
 capi.synchronize()
 c = capi.counters()
-rays = c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0)
+rays = c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0) - c.get("rays_shadow_skipped", 0)
 print({k: v for k, v in c.items()})
 capi.set_option(capi.OPT_COUNT_WORK, 0)
 best = 1e9

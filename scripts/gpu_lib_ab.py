@@ -37,6 +37,6 @@ rt.start()
 rt.raytrace(1, read_back=False)
 capi.synchronize()
 w = capi.counters()
-print("%s: %.4f ms per sample, traverse %.4f ms (camera rays %.4f), shade %.4f ms, node lines %d, triangle tests %d, frame sha %s, MIS rays not traced %d of %d bounce+MIS rays" % (
+print("%s: %.4f ms per sample, traverse %.4f ms (camera rays %.4f), shade %.4f ms, node lines %d, triangle tests %d, frame sha %s, MIS rays not traced %d of %d bounce+MIS rays, shadow rays not traced %d of %d" % (
     capi.LIB_PATH.split("/")[-1], best * 1e3, k["traverse_ms"] / 16, k["camera_traverse_ms"] / 16, k["shade_ms"] / 16, w["node_visits"], w["triangle_tests"],
-    hashlib.sha256(img.tobytes()).hexdigest()[:16], w.get("rays_mis_pretested", 0), w["rays_bounce"]))
+    hashlib.sha256(img.tobytes()).hexdigest()[:16], w.get("rays_mis_pretested", 0), w["rays_bounce"], w.get("rays_shadow_skipped", 0), w["rays_shadow"]))

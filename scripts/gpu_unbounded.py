@@ -28,7 +28,7 @@ for depth in (5, 0):
     capi.synchronize()
     dt = (time.perf_counter() - t0) / n
     c = capi.counters()
-    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0)) / n
+    rays = (c["rays_primary"] + c["rays_bounce"] + c["rays_shadow"] - c.get("rays_mis_pretested", 0) - c.get("rays_shadow_skipped", 0)) / n
     four = rt.temp_color_img2.read()
     print(f"max_depth {depth}: four calls {dt * 1e3:.3f} ms per sample, {rays / 1e6:.2f} Mrays, "
           f"{c['traverse_launches'] / n:.1f} traversal launches -> {rays / dt / 1e6:.0f} Mrays/s", flush=True)

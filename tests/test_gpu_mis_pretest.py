@@ -67,7 +67,8 @@ def test_frames_with_and_without_the_pretest_and_the_oracle(name, depth, request
             assert (a == b).all() and (a == r.view(np.uint32)).all()
         for k in (k_on, k_off):  # the schedule's calls are counted alike
             assert (k["rays_primary"], k["rays_bounce"], k["rays_shadow"], k["path_segments"]) == tuple(int(x) for x in cnt[:4])
-        assert k_off["rays_mis_pretested"] == 0
+        assert k_off["rays_mis_pretested"] == 0 and k_off["rays_shadow_skipped"] == 0
+        assert k_on["rays_shadow_skipped"] == int(cnt[7]) > 0
         if n_light_tris <= 16:
             assert k_on["rays_mis_pretested"] == int(cnt[6]) > 0
         else:  # more light triangles than the list holds: every MIS ray is traced
@@ -86,6 +87,7 @@ def test_the_validation_kernels_read_the_compacted_mis_rays_too(kernel, traversa
     for a, b in zip(base, other):
         assert (a == b).all()
     assert k0["rays_mis_pretested"] == k1["rays_mis_pretested"] > 0
+    assert k0["rays_shadow_skipped"] == k1["rays_shadow_skipped"] > 0
 
 
 def test_a_rewritten_meta_buffer_gets_a_new_list(request):
