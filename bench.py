@@ -593,7 +593,8 @@ def main():
                             f"fixed seed {SEED}+sample",
                 "frame": [width, height],
                 "tiles": "64x64 round-robin over ranks" if multi else "single GPU",
-                "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step"
+                "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step (four C-ABI calls that "
+                            "return once enqueued, NOVA_HIP_OPT_ASYNC_LAUNCH; the timed region ends with nova_hip_synchronize)"
                             + ("" if not multi else "; one all-gather of the finished tiles per run"
                                + (" (float4 means, FXAA + tone-map of the whole frame on rank 0)" if args.anti_aliasing
                                   else " (uchar4 pixels)")),

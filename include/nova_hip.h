@@ -387,6 +387,13 @@ enum {
                                     (nova_amd/csrc/shade.hpp gives the argument).  Likewise the shadow ray of a light
                                     sample whose term is +0 in every channel (light below the surface's horizon) is
                                     not traced: blocked or not, the same +0 is added.  0 traces every ray */
+  NOVA_HIP_OPT_ASYNC_LAUNCH = 12, /* 1 (default): nova_hip_launch_raytrace / _accumulate / _post_process and
+                                    nova_hip_image_copy return once their kernels are enqueued on the library's stream;
+                                    every other entry point first waits for what they left there, so reads, writes,
+                                    frees and option changes see what the blocking calls of the reference's backends
+                                    (queue.finish() / cudaDeviceSynchronize() after every kernel) would have left.  Code
+                                    that touches nova_hip_image::data with its own HIP calls calls nova_hip_synchronize
+                                    first.  0: each of the four waits for its own kernels */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

@@ -20,6 +20,7 @@ OPT_MAX_DEPTH, OPT_TRAVERSAL, OPT_COUNT_WORK, OPT_TILE_RANK, OPT_TILE_RANKS, OPT
 OPT_CLAMP_TO_EDGE = 9
 OPT_ALLOC_CALLS = 10  # read-only
 OPT_MIS_PRETEST = 11
+OPT_ASYNC_LAUNCH = 12
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 

@@ -170,6 +170,10 @@ struct Ctx {
   uint64_t lt_version = 0, lt_tri_version = 0;
   uint32_t lt_tris = 0;
   int64_t opt_mis_pretest = 1;
+  // NOVA_HIP_OPT_ASYNC_LAUNCH: the four per-sample calls return once their kernels are enqueued; `unsettled` = some
+  // of that work has not been waited for yet (settle())
+  int64_t opt_async = 1;
+  bool unsettled = false;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -308,6 +312,28 @@ void collect_events() {
   g.ev_used = 0;
 }
 
+// Every entry point other than the four per-sample launches starts here: whatever those left enqueued on the
+// library's stream (NOVA_HIP_OPT_ASYNC_LAUNCH) is waited for, so that reads, writes, frees and option changes see the
+// state a blocking call would have left.
+int settle() {
+  if (!g.ready || !g.unsettled) return 0;
+  g.unsettled = false;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  return 0;
+}
+// a per-sample launch is done enqueuing: wait (blocking mode) or leave it to settle()
+int launched() {
+  if (g.opt_async && g.ev_used < 8192) { // (the event pool of the timing spans grows until someone waits)
+    g.unsettled = true;
+    return 0;
+  }
+  g.unsettled = false;
+  HIP_TRY(hipStreamSynchronize(g.stream));
+  collect_events();
+  return 0;
+}
+
 void switch_lane(int to) {
   if (to == g.cur) return;
   Lane& o = g.lanes[g.cur];
@@ -393,6 +419,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
       return 0;
     }
   }
+  (void) hipStreamSynchronize(g.stream); // an earlier launch, not yet awaited, may still walk a layout that is dropped here
   drop_scenes_using(bvh); // stale entries for a rewritten buffer
   PackedScene s;
   // on the device where the array is a well-formed, nested tree (bvh_pack_device.hpp); else on the host
@@ -611,6 +638,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
 int ensure_frame_buffers(uint32_t paths) {
   FrameBuffers& fb = g.fb;
   if (fb.capacity >= paths) return 0;
+  (void) hipStreamSynchronize(g.stream); // kernels of an earlier, not yet awaited launch may still use the old ones
   auto release = [&]() {
     for (int s = 0; s < 2; s++) {
       for (int k = 0; k < 6; k++) { (void) hipFree(fb.planes[s][k]); fb.planes[s][k] = nullptr; }
@@ -875,6 +903,7 @@ int nova_hip_device_name(char* out, size_t out_bytes) {
 }
 
 int nova_hip_synchronize(void) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));
@@ -883,6 +912,7 @@ int nova_hip_synchronize(void) {
 }
 
 int nova_hip_shutdown(void) {
+  if (int rc_settle = settle()) return rc_settle;
   std::lock_guard<std::mutex> lock(g_mutex);
   if (!g.ready) return 0;
   (void) hipDeviceSynchronize();
@@ -924,14 +954,15 @@ int nova_hip_shutdown(void) {
   // (rays, kernel times) are per context and start again at zero.
   std::unordered_map<const void*, Alloc> allocs = std::move(g.allocs);
   const uint64_t next_version = g.next_version;
-  const int64_t opts[10] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
-                             g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays, g.opt_mis_pretest };
+  const int64_t opts[11] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
+                             g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays, g.opt_mis_pretest,
+                             g.opt_async };
   g = Ctx {};
   g.allocs = std::move(allocs);
   g.next_version = next_version;
   g.opt_max_depth = opts[0]; g.opt_traversal = opts[1]; g.opt_count_work = opts[2];
   g.opt_tile_rank = opts[3]; g.opt_tile_ranks = opts[4]; g.opt_kernel = opts[5];
-  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8]; g.opt_mis_pretest = opts[9];
+  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8]; g.opt_mis_pretest = opts[9]; g.opt_async = opts[10];
   return 0;
 }
 
@@ -948,6 +979,7 @@ int nova_hip_malloc(void** dev_ptr, size_t bytes) {
 }
 
 int nova_hip_free(void* dev_ptr) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!dev_ptr) return 0;
   auto it = g.allocs.find(dev_ptr);
   if (it == g.allocs.end()) return NOVA_HIP_E_UNKNOWN_BUFFER;
@@ -972,6 +1004,7 @@ int nova_hip_host_free(void* host_ptr) {
 }
 
 int nova_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!dst_dev || !src_host) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (bytes == 0) return 0;
   HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
@@ -980,6 +1013,7 @@ int nova_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
 }
 
 int nova_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!dst_host || !src_dev) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (bytes == 0) return 0;
   HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
@@ -987,6 +1021,7 @@ int nova_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
 }
 
 int nova_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!dst_dev || !src_dev) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (bytes == 0) return 0;
   HIP_TRY(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
@@ -995,6 +1030,7 @@ int nova_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes) {
 }
 
 int nova_hip_fill(void* dst_dev, const void* pattern, size_t pattern_bytes, size_t count) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!dst_dev || !pattern) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (count == 0) return 0;
   int rc = require_ctx();
@@ -1040,6 +1076,7 @@ int nova_hip_image_create(nova_hip_image** image, uint32_t texel_bytes, uint32_t
 }
 
 int nova_hip_image_destroy(nova_hip_image* image) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!image) return 0;
   hipError_t e = hipFree(image->data);
   delete image;
@@ -1051,12 +1088,14 @@ static size_t image_bytes(const nova_hip_image* im) {
 }
 
 int nova_hip_image_read(const nova_hip_image* image, void* host_dst) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!image || !image->data || !host_dst) return NOVA_HIP_E_INVALID_ARGUMENT;
   HIP_TRY(hipMemcpy(host_dst, image->data, image_bytes(image), hipMemcpyDeviceToHost));
   return 0;
 }
 
 int nova_hip_image_write(nova_hip_image* image, const void* host_src) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!image || !image->data || !host_src) return NOVA_HIP_E_INVALID_ARGUMENT;
   HIP_TRY(hipMemcpy(image->data, host_src, image_bytes(image), hipMemcpyHostToDevice));
   return 0;
@@ -1068,8 +1107,7 @@ int nova_hip_image_copy(nova_hip_image* dst, const nova_hip_image* src) {
   int rc = require_ctx();
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(dst->data, src->data, image_bytes(dst), hipMemcpyDeviceToDevice, g.stream));
-  HIP_TRY(hipStreamSynchronize(g.stream));
-  return 0;
+  return launched();
 }
 
 int nova_hip_image_fill(nova_hip_image* image, const void* texel) {
@@ -1080,6 +1118,7 @@ int nova_hip_image_fill(nova_hip_image* image, const void* texel) {
 
 // ---- options / counters ------------------------------------------------------------------------
 int nova_hip_set_option(int option, int64_t value) {
+  if (int rc_settle = settle()) return rc_settle;
   switch (option) {
     case NOVA_HIP_OPT_MAX_DEPTH:
       if (value < 0 || value >= kMaxIterations) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1107,6 +1146,9 @@ int nova_hip_set_option(int option, int64_t value) {
     case NOVA_HIP_OPT_MIS_PRETEST:
       if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_mis_pretest = value; return 0;
+    case NOVA_HIP_OPT_ASYNC_LAUNCH:
+      if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_async = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1124,12 +1166,14 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_SORT_RAYS: *value = g.opt_sort_rays; return 0;
     case NOVA_HIP_OPT_CLAMP_TO_EDGE: *value = g.opt_clamp_to_edge; return 0;
     case NOVA_HIP_OPT_MIS_PRETEST: *value = g.opt_mis_pretest; return 0;
+    case NOVA_HIP_OPT_ASYNC_LAUNCH: *value = g.opt_async; return 0;
     case NOVA_HIP_OPT_ALLOC_CALLS: *value = static_cast<int64_t>(g_alloc_calls.load()); return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
 
 int nova_hip_get_counters(nova_hip_counters* out) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!out) return NOVA_HIP_E_INVALID_ARGUMENT;
   int rc = require_ctx();
   if (rc) return rc;
@@ -1160,6 +1204,7 @@ int nova_hip_get_counters(nova_hip_counters* out) {
 }
 
 int nova_hip_reset_counters(void) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(g.stream));
@@ -1413,8 +1458,13 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
                              const nova_hip_image* materials, const nova_hip_image* sky,
                              uint32_t denoise_available, nova_hip_image* albedo_feature1,
                              nova_hip_image* normal_feature1) {
-  return raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
-                       materials, sky, denoise_available, albedo_feature1, normal_feature1, true);
+  int rc = raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
+                         materials, sky, denoise_available, albedo_feature1, normal_feature1, false);
+  if (rc) {
+    (void) settle();
+    return rc;
+  }
+  return launched();
 }
 
 // NOVA_HIP_OPT_CLAMP_TO_EDGE for an image created with NOVA_ADDRESS_CLAMP
@@ -1478,9 +1528,10 @@ int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
                                const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
                                nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
                                uint32_t width, uint32_t height) {
-  return accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
-                         prev_albedo_feature, prev_normal_feature, temp_color2, albedo_feature2, normal_feature2,
-                         width, height, true);
+  int rc = accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
+                           prev_albedo_feature, prev_normal_feature, temp_color2, albedo_feature2, normal_feature2,
+                           width, height, false);
+  return rc ? rc : launched();
 }
 
 // ---- kernel_post_process -----------------------------------------------------------------------
@@ -1514,8 +1565,7 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
   const unsigned blocks = std::min<unsigned>((n + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
   hipLaunchKernelGGL(k_post_process, dim3(blocks), dim3(256), 0, g.stream, A);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(g.stream));
-  return 0;
+  return launched();
 }
 
 // ---- several samples in one call ---------------------------------------------------------------
@@ -1566,6 +1616,7 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
                             const nova_area_light* lights, uint32_t num_lights,
                             const nova_hip_image* materials, const nova_hip_image* sky,
                             uint32_t denoise_available) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!params || !times || !images || num_samples == 0 || first_sample_index < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1691,11 +1742,13 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
                        : nova_hip_launch_post_process(params, &color[in], I.pixels, width, height); // waits for this lane
   wait_all(); // the other lanes are done already: their last kernels were waited for by this one's
   collect_events();
+  g.unsettled = false;
   return rc;
 }
 
 // ---- roofline denominators -----------------------------------------------------------------------
 int nova_hip_measure_device(nova_hip_device_rates* out) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!out) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1757,6 +1810,7 @@ static int ensure_denoise_planes(size_t pixels) {
 
 int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* albedo, const nova_hip_image* normal,
                           uint32_t width, uint32_t height, nova_hip_denoise_planes* planes) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!planes || width == 0 || height == 0 || !float_image_ok(color, width, height) ||
@@ -1790,6 +1844,7 @@ int nova_hip_denoise_read(const nova_hip_image* color, const nova_hip_image* alb
 }
 
 int nova_hip_denoise_write(nova_hip_image* color, uint32_t width, uint32_t height) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (width == 0 || height == 0 || !float_image_ok(color, width, height)) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1844,6 +1899,7 @@ static int tiles_unpack_async(nova_hip_image* image, uint32_t ranks, const void*
 }
 
 int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ranks, void* stack_dev) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!tile_image_ok(image) || !stack_dev || ranks == 0 || rank >= ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1854,6 +1910,7 @@ int nova_hip_tiles_pack(const nova_hip_image* image, uint32_t rank, uint32_t ran
 }
 
 int nova_hip_tiles_unpack(nova_hip_image* image, uint32_t ranks, const void* stacks_dev) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!tile_image_ok(image) || !stacks_dev || ranks == 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1884,6 +1941,7 @@ static void drop_comm() {
 }
 
 int nova_hip_tiles_comm_init(const void* unique_id, uint32_t rank, uint32_t ranks) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!unique_id || ranks == 0 || rank >= ranks) return NOVA_HIP_E_INVALID_ARGUMENT;
   int rc = require_ctx();
   if (rc) return rc;
@@ -1903,6 +1961,7 @@ int nova_hip_tiles_comm_init(const void* unique_id, uint32_t rank, uint32_t rank
 }
 
 int nova_hip_tiles_comm_adopt(void* nccl_comm) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!nccl_comm) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1921,6 +1980,7 @@ int nova_hip_tiles_comm_adopt(void* nccl_comm) {
 }
 
 int nova_hip_tiles_comm_destroy(void) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!g.ready) return 0;
   (void) hipStreamSynchronize(g.stream);
   drop_comm();
@@ -1948,6 +2008,7 @@ int nova_hip_tiles_comm_info(nova_hip_comm_info* out) {
 // collective of equal-sized stacks.  Afterwards EVERY rank's image holds every rank's tiles: an all-gather hands the
 // stacks to everyone anyway, and the unpack is one streaming pass (4K float4: 0.13 GB).
 int nova_hip_tiles_allgather(nova_hip_image* image) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!tile_image_ok(image)) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1978,6 +2039,7 @@ int nova_hip_tiles_allgather(nova_hip_image* image) {
 int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
                         const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
                         nova_float4* hits, uint64_t num_rays) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!triangles || !bvh || !rays_point_tmax || !rays_dir_flags || !hits) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -2059,6 +2121,7 @@ int nova_hip_trace_rays(const nova_triangle_data* triangles, const nova_bvh_node
 int nova_hip_trace_rays_noalloc(const nova_triangle_data* triangles, const nova_bvh_node* bvh,
                                 const nova_float4* rays_point_tmax, const nova_float4* rays_dir_flags,
                                 nova_float4* hits, uint64_t num_rays) {
+  if (int rc_settle = settle()) return rc_settle;
   if (!g.ready || !g.scratch_ptr) return NOVA_HIP_E_NO_DEVICE; // nova_hip_init makes the context (it allocates)
   if (!triangles || !bvh || !rays_point_tmax || !rays_dir_flags || !hits) return NOVA_HIP_E_INVALID_ARGUMENT;
   if (num_rays == 0) return 0;
@@ -2113,6 +2176,7 @@ uint64_t nova_hip_bvh_max_nodes(uint64_t num_triangles) { return bvhb::max_nodes
 int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
                               uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
                               uint32_t* order_out, nova_hip_build_stats* stats) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!vertices || !bvh_out || !num_nodes || !triangles_out || !order_out || num_triangles == 0)
@@ -2164,6 +2228,7 @@ int nova_hip_build_bvh_device(const float* vertices, uint64_t num_triangles, nov
 int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_node* bvh_out,
                        uint64_t bvh_capacity, uint64_t* num_nodes, nova_triangle_data* triangles_out,
                        uint32_t* order_out, nova_hip_build_stats* stats) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!vertices || !bvh_out || !num_nodes || !triangles_out || !order_out || num_triangles == 0)
@@ -2200,6 +2265,7 @@ int nova_hip_build_bvh(const float* vertices, uint64_t num_triangles, nova_bvh_n
 
 int nova_hip_validate_scene_pack(const nova_bvh_node* bvh, const nova_triangle_data* triangles,
                                  uint64_t* different_words) {
+  if (int rc_settle = settle()) return rc_settle;
   int rc = require_ctx();
   if (rc) return rc;
   if (!bvh || !triangles || !different_words) return NOVA_HIP_E_INVALID_ARGUMENT;

@@ -14,6 +14,8 @@ rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
 if os.environ.get("NOVA_AB_MIS_PRETEST") is not None and hasattr(capi, "OPT_MIS_PRETEST"):
     capi.set_option(capi.OPT_MIS_PRETEST, int(os.environ["NOVA_AB_MIS_PRETEST"]))
+if os.environ.get("NOVA_AB_ASYNC") is not None and hasattr(capi, "OPT_ASYNC_LAUNCH"):
+    capi.set_option(capi.OPT_ASYNC_LAUNCH, int(os.environ["NOVA_AB_ASYNC"]))
 if len(sys.argv) > 1:
     capi.set_option(capi.OPT_TRAVERSE_KERNEL, int(sys.argv[1]))
 rt.start()
