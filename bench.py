@@ -594,7 +594,8 @@ def main():
                 "frame": [width, height],
                 "tiles": "64x64 round-robin over ranks" if multi else "single GPU",
                 "schedule": "kernel_raytrace + kernel_accumulate + copy + kernel_post_process per step (four C-ABI calls that "
-                            "return once enqueued, NOVA_HIP_OPT_ASYNC_LAUNCH; the timed region ends with nova_hip_synchronize)"
+                            "return once enqueued, NOVA_HIP_OPT_ASYNC_LAUNCH; kernel_raytrace of successive steps on three "
+                            "lanes in turn, NOVA_HIP_OPT_CALL_LANES; the timed region ends with nova_hip_synchronize)"
                             + ("" if not multi else "; one all-gather of the finished tiles per run"
                                + (" (float4 means, FXAA + tone-map of the whole frame on rank 0)" if args.anti_aliasing
                                   else " (uchar4 pixels)")),
@@ -653,27 +654,57 @@ def main():
                 "valu_frac": round(valu_ops_per_ray * rays_per_s / (FP32_VECTOR_PEAK_TFLOPS * 1e12 / 2.0), 4),
                 "valu_frac_of_measured": round(valu_ops_per_ray * rays_per_s / valu_rate_measured, 4),
             })
+            # The timed region runs kernel_raytrace of up to three samples side by side (NOVA_HIP_OPT_CALL_LANES), so a
+            # launch there shares the GPU with other samples' kernels.  The same K steps once more, one sample at a time:
+            # the kernel alone on the GPU, which is also how rocprofv3's counter passes see it (they serialise dispatches).
+            capi.set_option(capi.OPT_CALL_LANES, 1)
+            rt.start()
+            rt.raytrace(rt.step_time(SEED), read_back=False)
+            rt.start()
+            capi.reset_counters()
+            i0 = time.perf_counter()
+            for _ in range(args.steps):
+                rt.raytrace(rt.step_time(SEED), read_back=False)
+            capi.synchronize()
+            idt = time.perf_counter() - i0
+            ki = capi.counters()
+            capi.set_option(capi.OPT_CALL_LANES, 0)
+            il = max(1, int(ki["traverse_launches"]) - int(ki["camera_traverse_launches"]))
+            iso_launch_s = (ki["traverse_ms"] - ki["camera_traverse_ms"]) / il / 1e3
+            iso_achieved = bytes_per_launch / iso_launch_s / 1e9
+            roof["one_sample_at_a_time"] = {
+                "how": "the same K steps with NOVA_HIP_OPT_CALL_LANES = 1: kernels never share the GPU (the counter fields "
+                       "below are priced against this launch time: counter passes serialise dispatches)",
+                "ms_per_step": round(idt / args.steps * 1e3, 4), "avg_launch_ms": round(iso_launch_s * 1e3, 4),
+                "achieved": round(iso_achieved, 1), "frac": round(iso_achieved / HBM_PEAK_GBS, 4),
+                "camera_ray_kernel_ms": round(ki["camera_traverse_ms"] / max(1, int(ki["camera_traverse_launches"])), 4),
+                "shade_ms_per_step": round(ki["shade_ms"] / args.steps, 4),
+            }
             # the same kernel against the bytes of the tree it really walks (four-wide nodes of 128 B)
             ww = walked_work(capi, rt, params, SEED)
             if ww:
                 wa = ww["bytes_per_ray"] * rays_k / launches / avg_launch_s / 1e9
+                wi = ww["bytes_per_ray"] * rays_k / launches / iso_launch_s / 1e9
                 roof["walked"] = {"model": "128 B x four-wide nodes + 48 B x triangle tests + 64 B per ray, counted on the device "
                                            "(NOVA_HIP_OPT_COUNT_WORK, one sample)",
                                   "wide_nodes_per_ray": round(ww["wide_nodes_per_ray"], 2),
                                   "tri_tests_per_ray": round(ww["tri_tests_per_ray"], 2),
                                   "bytes_per_ray": round(ww["bytes_per_ray"], 1), "achieved": round(wa, 1),
-                                  "frac": round(wa / HBM_PEAK_GBS, 4)}
+                                  "frac": round(wa / HBM_PEAK_GBS, 4),
+                                  "frac_one_sample_at_a_time": round(wi / HBM_PEAK_GBS, 4)}
             # what the counters say (profiles/, rocprofv3 passes of scripts/prof_run.py on the same frame)
             pj = load_pmc("pmc_traffic.json")
-            counters_view(roof, pj, avg_launch_s, rays_k / launches, rates)
+            counters_view(roof, pj, iso_launch_s, rays_k / launches, rates)
             if roof["bound"] is None:  # no counter file: say what the measured denominators say
                 roof["bound"] = "unknown (profiles/pmc_traffic.json missing)"
             cam_pj = pj.get("camera_ray_kernel") if pj else None
             # camera rays: the packet kernel fetches a node once per 64 rays through the scalar cache, so a
             # per-ray byte model says nothing about it; it is bound by instruction issue (VALU + SALU ports)
-            cam_s = k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])) / 1e3
+            cam_timed_s = k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])) / 1e3
+            cam_s = ki["camera_traverse_ms"] / max(1, int(ki["camera_traverse_launches"])) / 1e3  # alone on the GPU
             wave_issue_measured = rates["fp32_fma_tflops"] * 1e12 / 128.0
             cam = {"kernel": "k_traverse_packet", "avg_launch_ms": round(cam_s * 1e3, 4),
+                   "avg_launch_ms_timed_region": round(cam_timed_s * 1e3, 4),
                    "rays_per_launch": int(local[0]) // max(1, int(k["camera_traverse_launches"])),
                    "bound": "instruction issue + dependent scalar-load latency (wave-uniform node and triangle fetches through the scalar cache)",
                    "algorithmic_valu_frac": round((17.0 * n_node_cam + 33.0 * n_tri_cam) * int(local[0]) /

@@ -394,6 +394,14 @@ enum {
                                     (queue.finish() / cudaDeviceSynchronize() after every kernel) would have left.  Code
                                     that touches nova_hip_image::data with its own HIP calls calls nova_hip_synchronize
                                     first.  0: each of the four waits for its own kernels */
+  NOVA_HIP_OPT_CALL_LANES = 13, /* with NOVA_HIP_OPT_ASYNC_LAUNCH: successive nova_hip_launch_raytrace calls take turns on
+                                   this many lanes (own stream, path state and radiance planes each; 1-4, 0 = built-in 3),
+                                   so that the kernel_raytrace of one sample runs beside the latency-bound tail and the
+                                   image kernels of the sample before.  Each lane renders into planes of its own and
+                                   copies them into temp_color1 / the feature images once every call made before it is
+                                   done with those images: the images hold what one lane would have left.  One lane
+                                   when paths are unbounded (NOVA_HIP_OPT_MAX_DEPTH 0).  Costs one set of path state
+                                   per extra lane (0.9 GB at 1080p) */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

@@ -21,6 +21,7 @@ OPT_CLAMP_TO_EDGE = 9
 OPT_ALLOC_CALLS = 10  # read-only
 OPT_MIS_PRETEST = 11
 OPT_ASYNC_LAUNCH = 12
+OPT_CALL_LANES = 13
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 

@@ -296,6 +296,13 @@ __global__ __launch_bounds__(256) void k_measure_fma(float* out, int iterations,
 }
 
 // dst[i] = pattern (1..16 bytes), for Buffer::fill / fill_image2D
+// dst[i] = src[i] for the pixels this rank renders (tile-plan mask != 0); the others keep what they hold
+__global__ __launch_bounds__(256) void k_copy_kept(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                   const uint8_t* __restrict__ mask, uint32_t n_pixels) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x)
+    if (mask[i]) dst[i] = src[i];
+}
+
 template <typename T>
 __global__ void k_fill(T* dst, T value, size_t count) {
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < count;

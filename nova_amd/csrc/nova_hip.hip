@@ -173,6 +173,7 @@ struct Ctx {
   // NOVA_HIP_OPT_ASYNC_LAUNCH: the four per-sample calls return once their kernels are enqueued; `unsettled` = some
   // of that work has not been waited for yet (settle())
   int64_t opt_async = 1;
+  int64_t opt_call_lanes = 0; // NOVA_HIP_OPT_CALL_LANES: 0 = built-in (kDefaultLanes, env NOVA_HIP_CALL_LANES)
   bool unsettled = false;
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
@@ -196,6 +197,11 @@ struct Ctx {
   hipEvent_t acc_done[2] = { nullptr, nullptr }; // recorded after kernel_accumulate of even / odd samples
   float4* stage[kMaxLanes - 1][3] = {}; // temp_color1 / albedo1 / normal1 of the lanes that do not render the last sample
   size_t stage_bytes = 0;
+  // per-call overlap (nova_hip_launch_raytrace with NOVA_HIP_OPT_ASYNC_LAUNCH): every lane renders into planes of its
+  // own and copies them into the caller's images once the image work enqueued before it is done (lane_mark)
+  float4* call_stage[kMaxLanes][3] = {};
+  size_t call_stage_bytes = 0;
+  hipEvent_t lane_mark[kMaxLanes] = {};
 };
 
 Ctx g;
@@ -318,7 +324,9 @@ void collect_events() {
 int settle() {
   if (!g.ready || !g.unsettled) return 0;
   g.unsettled = false;
-  HIP_TRY(hipStreamSynchronize(g.stream));
+  HIP_TRY(hipStreamSynchronize(g.stream)); // the current lane holds the newest work, which waited for the others'
+  for (int l = 0; l < g.lanes_ready; l++)
+    if (l != g.cur && g.lanes[l].stream) HIP_TRY(hipStreamSynchronize(g.lanes[l].stream));
   collect_events();
   return 0;
 }
@@ -419,7 +427,7 @@ int get_scene(const nova_bvh_node* bvh, const nova_triangle_data* tris, PackedSc
       return 0;
     }
   }
-  (void) hipStreamSynchronize(g.stream); // an earlier launch, not yet awaited, may still walk a layout that is dropped here
+  (void) hipDeviceSynchronize(); // an earlier launch on any lane, not yet awaited, may still walk a layout that is dropped here
   drop_scenes_using(bvh); // stale entries for a rewritten buffer
   PackedScene s;
   // on the device where the array is a well-formed, nested tree (bvh_pack_device.hpp); else on the host
@@ -947,6 +955,10 @@ int nova_hip_shutdown(void) {
     for (auto& p : lane) (void) hipFree(p);
   for (auto& e : g.acc_done)
     if (e) (void) hipEventDestroy(e);
+  for (auto& e : g.lane_mark)
+    if (e) (void) hipEventDestroy(e);
+  for (auto& lane : g.call_stage)
+    for (auto& p : lane) (void) hipFree(p);
   for (hipEvent_t e : g.ev_pool) (void) hipEventDestroy(e);
   for (auto& pd : g_pending) pd = Pending {};
   // buffers from nova_hip_malloc belong to the caller and stay valid; the registry goes with them
@@ -954,15 +966,15 @@ int nova_hip_shutdown(void) {
   // (rays, kernel times) are per context and start again at zero.
   std::unordered_map<const void*, Alloc> allocs = std::move(g.allocs);
   const uint64_t next_version = g.next_version;
-  const int64_t opts[11] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
+  const int64_t opts[12] = { g.opt_max_depth, g.opt_traversal, g.opt_count_work, g.opt_tile_rank, g.opt_tile_ranks,
                              g.opt_kernel, g.opt_tune, g.opt_clamp_to_edge, g.opt_sort_rays, g.opt_mis_pretest,
-                             g.opt_async };
+                             g.opt_async, g.opt_call_lanes };
   g = Ctx {};
   g.allocs = std::move(allocs);
   g.next_version = next_version;
   g.opt_max_depth = opts[0]; g.opt_traversal = opts[1]; g.opt_count_work = opts[2];
   g.opt_tile_rank = opts[3]; g.opt_tile_ranks = opts[4]; g.opt_kernel = opts[5];
-  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8]; g.opt_mis_pretest = opts[9]; g.opt_async = opts[10];
+  g.opt_tune = opts[6]; g.opt_clamp_to_edge = opts[7]; g.opt_sort_rays = opts[8]; g.opt_mis_pretest = opts[9]; g.opt_async = opts[10]; g.opt_call_lanes = opts[11];
   return 0;
 }
 
@@ -1149,6 +1161,9 @@ int nova_hip_set_option(int option, int64_t value) {
     case NOVA_HIP_OPT_ASYNC_LAUNCH:
       if (value < 0 || value > 1) return NOVA_HIP_E_INVALID_ARGUMENT;
       g.opt_async = value; return 0;
+    case NOVA_HIP_OPT_CALL_LANES:
+      if (value < 0 || value > kMaxLanes) return NOVA_HIP_E_INVALID_ARGUMENT;
+      g.opt_call_lanes = value; return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
 }
@@ -1167,6 +1182,7 @@ int nova_hip_get_option(int option, int64_t* value) {
     case NOVA_HIP_OPT_CLAMP_TO_EDGE: *value = g.opt_clamp_to_edge; return 0;
     case NOVA_HIP_OPT_MIS_PRETEST: *value = g.opt_mis_pretest; return 0;
     case NOVA_HIP_OPT_ASYNC_LAUNCH: *value = g.opt_async; return 0;
+    case NOVA_HIP_OPT_CALL_LANES: *value = g.opt_call_lanes; return 0;
     case NOVA_HIP_OPT_ALLOC_CALLS: *value = static_cast<int64_t>(g_alloc_calls.load()); return 0;
     default: return NOVA_HIP_E_INVALID_ARGUMENT;
   }
@@ -1300,6 +1316,27 @@ static int ensure_light_tris(const nova_triangle_meta* meta, const Alloc* am, co
   g.lt_tri_ptr = tris;
   g.lt_tri_version = at->version;
   g.lt_tris = n_tris;
+  return 0;
+}
+
+static int ensure_lanes(int lanes, size_t plane_bytes, bool features);
+static int ensure_call_lanes(int lanes, size_t plane_bytes, bool features) {
+  int rc = ensure_lanes(lanes, 0, false);
+  if (rc) return rc;
+  for (int l = 0; l < lanes; l++)
+    if (!g.lane_mark[l]) HIP_TRY(hipEventCreateWithFlags(&g.lane_mark[l], hipEventDisableTiming));
+  if (plane_bytes > g.call_stage_bytes) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& lane : g.call_stage)
+      for (auto& p : lane) { (void) hipFree(p); p = nullptr; }
+    g.call_stage_bytes = plane_bytes;
+  }
+  for (int l = 0; l < lanes; l++)
+    for (int k = 0; k < (features ? 3 : 1); k++)
+      if (!g.call_stage[l][k]) {
+        HIP_TRY(hipMalloc(&g.call_stage[l][k], g.call_stage_bytes));
+        HIP_TRY(hipMemset(g.call_stage[l][k], 0, g.call_stage_bytes));
+      }
   return 0;
 }
 
@@ -1458,8 +1495,72 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
                              const nova_hip_image* materials, const nova_hip_image* sky,
                              uint32_t denoise_available, nova_hip_image* albedo_feature1,
                              nova_hip_image* normal_feature1) {
-  int rc = raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
-                         materials, sky, denoise_available, albedo_feature1, normal_feature1, false);
+  int rc = require_ctx();
+  if (rc) return rc;
+  // Lanes in turn (as nova_hip_render_samples does inside one call): kernel_raytrace of this call runs on the next
+  // lane's stream with that lane's path state, beside the latency-bound tail and the image kernels of the call before.
+  // It renders into the lane's own planes; those are copied into the caller's images once everything enqueued before
+  // this call — which may still read the images — is done.  Not under a tile partition (kernel_raytrace leaves other
+  // ranks' pixels of temp_color1 as they are), not with unbounded paths (the host looks at the survivor count between
+  // iterations), not in blocking mode.
+  static const int env_lanes = [] {
+    const char* e = std::getenv("NOVA_HIP_CALL_LANES");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= kMaxLanes ? v : kDefaultLanes;
+  }();
+  const bool images_ok = float_image_ok(temp_color1, width, height) &&
+                         (!denoise_available || (float_image_ok(albedo_feature1, width, height) &&
+                                                 float_image_ok(normal_feature1, width, height)));
+  const int want = g.opt_call_lanes >= 1 ? static_cast<int>(g.opt_call_lanes) : env_lanes;
+  const int L = (g.opt_async && g.opt_max_depth != 0 && images_ok && params && params->path_tracing &&
+                 g.opt_tile_rank < g.opt_tile_ranks) ? want : 1;
+  if (L > 1) {
+    const size_t plane = static_cast<size_t>(width) * height * 16;
+    rc = ensure_call_lanes(L, plane, denoise_available != 0);
+    if (rc) return rc;
+    const int prev = g.cur;
+    HIP_TRY(hipEventRecord(g.lane_mark[prev], g.stream));
+    switch_lane((prev + 1) % L);
+    nova_hip_image color = *temp_color1, albedo, normal;
+    color.data = g.call_stage[g.cur][0];
+    if (denoise_available) {
+      albedo = *albedo_feature1; albedo.data = g.call_stage[g.cur][1];
+      normal = *normal_feature1; normal.data = g.call_stage[g.cur][2];
+    }
+    rc = raytrace_impl(params, time, &color, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
+                       denoise_available, denoise_available ? &albedo : nullptr, denoise_available ? &normal : nullptr, false);
+    if (rc == 0) {
+      hipError_t e = hipStreamWaitEvent(g.stream, g.lane_mark[prev], 0);
+      const int n_planes = denoise_available ? 3 : 1;
+      float4* const dst[3] = { static_cast<float4*>(temp_color1->data),
+                               denoise_available ? static_cast<float4*>(albedo_feature1->data) : nullptr,
+                               denoise_available ? static_cast<float4*>(normal_feature1->data) : nullptr };
+      if (g.opt_tile_ranks > 1) {
+        // kernel_raytrace writes this rank's pixels only; so does the copy
+        if (e == hipSuccess && ensure_tile_plan(width, height) != 0) e = hipErrorUnknown;
+        const uint32_t n_pixels = width * height;
+        const unsigned blocks = std::min<unsigned>((n_pixels + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+        for (int k = 0; k < n_planes && e == hipSuccess; k++) {
+          hipLaunchKernelGGL(k_copy_kept, dim3(blocks), dim3(256), 0, g.stream, dst[k], g.call_stage[g.cur][k], g.plan.d_mask, n_pixels);
+          e = hipGetLastError();
+        }
+      } else {
+        for (int k = 0; k < n_planes && e == hipSuccess; k++)
+          e = hipMemcpyAsync(dst[k], g.call_stage[g.cur][k], plane, hipMemcpyDeviceToDevice, g.stream);
+      }
+      g.chain_tail = nullptr;
+      rc = static_cast<int>(e);
+    }
+    g.unsettled = true;
+    if (rc) {
+      (void) settle();
+      return rc;
+    }
+    return launched();
+  }
+  rc = raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
+                     materials, sky, denoise_available, albedo_feature1, normal_feature1, false);
+  g.unsettled = true;
   if (rc) {
     (void) settle();
     return rc;
@@ -1592,6 +1693,7 @@ static int ensure_lanes(int lanes, size_t plane_bytes, bool features) {
       for (auto& p : lane) { (void) hipFree(p); p = nullptr; }
     g.stage_bytes = plane_bytes;
   }
+  if (plane_bytes == 0) return 0; // lanes only (ensure_call_lanes)
   for (int l = 0; l + 1 < lanes; l++)
     for (int k = 0; k < (features ? 3 : 1); k++)
       if (!g.stage[l][k]) HIP_TRY(hipMalloc(&g.stage[l][k], g.stage_bytes));

@@ -15,11 +15,13 @@ def device():
     capi.init(0)
     yield
     capi.set_option(capi.OPT_ASYNC_LAUNCH, 1)
+    capi.set_option(capi.OPT_CALL_LANES, 0)
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
 
 
-def run(knot_small, mode, samples=5, w=200, h=136):
+def run(knot_small, mode, samples=5, w=200, h=136, lanes=0):
     capi.set_option(capi.OPT_ASYNC_LAUNCH, mode)
+    capi.set_option(capi.OPT_CALL_LANES, lanes)
     capi.set_option(capi.OPT_MAX_DEPTH, 5)
     p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), shading_metallic=0.4, shading_roughness=0.1)
     rt = Raytracer(0, denoise_available=True)
@@ -44,6 +46,27 @@ def test_the_images_and_counters_are_those_of_blocking_calls(knot_small):
                  "rays_shadow_skipped"):
         assert ka[name] == kb[name]
     assert ka["traverse_ms"] > 0 and ka["shade_ms"] > 0  # the timing spans were collected by the entry point that waited
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_lanes_in_turn_leave_the_images_of_one_lane(knot_small, lanes):
+    """NOVA_HIP_OPT_CALL_LANES: kernel_raytrace of successive calls on 1-4 lanes; seven samples, so that every lane is
+    used more than once and the last sample's lane is not the first's."""
+    a, ka = run(knot_small, 1, samples=7, lanes=lanes)
+    b, kb = run(knot_small, 0, samples=7)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    for name in ("rays_primary", "rays_bounce", "rays_shadow", "path_segments", "traverse_launches"):
+        assert ka[name] == kb[name]
+
+
+def test_a_change_of_frame_size_between_calls(knot_small):
+    """The lanes' own planes grow with the frame; a smaller frame afterwards reuses them."""
+    for w, h in ((96, 64), (200, 136), (64, 64)):
+        a, _ = run(knot_small, 1, samples=4, w=w, h=h)
+        b, _ = run(knot_small, 0, samples=4, w=w, h=h)
+        for x, y in zip(a, b):
+            assert (x == y).all()
 
 
 def test_writes_frees_and_option_changes_wait_for_enqueued_launches(knot_small):
