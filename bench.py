@@ -719,6 +719,12 @@ def main():
                 out["configs"] = other_configs(capi, S, Raytracer, rates, [c for c in args.configs.split(",") if c])
         else:
             out["cpu_baseline"] = None
+            # no oracle, no byte model: still say how long the dominant kernel's launches took by the library's HIP
+            # events, so that a rocprofv3 --kernel-trace --stats run of this very process can be held against it
+            launches = max(1, int(local[3]) - int(k["camera_traverse_launches"]))
+            roof.update({"avg_launch_ms": round((k["traverse_ms"] - k["camera_traverse_ms"]) / launches, 4), "launches": launches,
+                         "camera_ray_kernel": {"kernel": "k_traverse_packet", "avg_launch_ms_timed_region": round(
+                             k["camera_traverse_ms"] / max(1, int(k["camera_traverse_launches"])), 4)}})
         out["roofline"] = roof
         if fused is not None:
             out["fused_samples"] = fused
