@@ -555,6 +555,10 @@ constexpr size_t kCacheResidentBytes = 256u << 20; // nodes + triangles up to th
 #ifndef NOVA_P_MINWAVES
 #define NOVA_P_MINWAVES 5 // A/B builds only (build_ab/): waves per SIMD the persistent kernel is compiled for
 #endif
+#ifndef NOVA_P_REFILL
+#define NOVA_P_REFILL 32   // A/B builds only: idle lanes that trigger a refill, helper lanes in the leaf step
+#define NOVA_P_HELP true
+#endif
 constexpr int kWideBlocksPerCu = NOVA_P_MINWAVES; // = the resident work-groups at 5 waves/SIMD (8 was 0-10 % slower on launches below 0.3 M rays)
 
 // k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
@@ -590,8 +594,8 @@ int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
       if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 16, NOVA_P_MINWAVES, false>), grid, block, 0, g.stream, A);
       else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 16, NOVA_P_MINWAVES, false>), grid, block, 0, g.stream, A);
     } else {
-      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, 32, NOVA_P_MINWAVES, true>), grid, block, 0, g.stream, A);
-      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, 32, NOVA_P_MINWAVES, true>), grid, block, 0, g.stream, A);
+      if (count) hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, true, NOVA_P_REFILL, NOVA_P_MINWAVES, NOVA_P_HELP>), grid, block, 0, g.stream, A);
+      else hipLaunchKernelGGL((k_traverse_p<kWideLdsStack, false, NOVA_P_REFILL, NOVA_P_MINWAVES, NOVA_P_HELP>), grid, block, 0, g.stream, A);
     }
     return static_cast<int>(hipGetLastError());
   }
