@@ -11,8 +11,10 @@
  * Conventions
  *   - every function returns 0 on success, otherwise a hipError_t value (>0) or one of the
  *     NOVA_HIP_E_* codes (<0); nothing throws across this boundary;
- *   - calls are synchronous like the reference's (`cudaDeviceSynchronize()` after every launch,
- *     src/backend/cuda/accelerator/accelerator.hpp:26-29), single host thread per device;
+ *   - what a caller can observe is what the reference's synchronous calls leave (`cudaDeviceSynchronize()` after
+ *     every launch, src/backend/cuda/accelerator/accelerator.hpp:26-29): the four per-sample launches
+ *     (nova_hip_launch_raytrace / _accumulate / _post_process, nova_hip_image_copy) return once enqueued and every other
+ *     entry point waits for them first (NOVA_HIP_OPT_ASYNC_LAUNCH = 0: each waits itself); single host thread per device;
  *   - device pointers handed to the launchers must come from nova_hip_malloc (the library keeps
  *     a ptr -> size registry so that the launchers know how many nodes/triangles a buffer holds:
  *     the reference's kernels receive bare pointers, kernels/kernels.cu:13-16).
