@@ -1504,9 +1504,9 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   // Lanes in turn (as nova_hip_render_samples does inside one call): kernel_raytrace of this call runs on the next
   // lane's stream with that lane's path state, beside the latency-bound tail and the image kernels of the call before.
   // It renders into the lane's own planes; those are copied into the caller's images once everything enqueued before
-  // this call — which may still read the images — is done.  Not under a tile partition (kernel_raytrace leaves other
-  // ranks' pixels of temp_color1 as they are), not with unbounded paths (the host looks at the survivor count between
-  // iterations), not in blocking mode.
+  // this call — which may still read the images — is done (under a tile partition only this rank's pixels: kernel_raytrace
+  // leaves the others of temp_color1 as they are).  One lane with unbounded paths (the host looks at the survivor count
+  // between iterations) and in blocking mode.
   static const int env_lanes = [] {
     const char* e = std::getenv("NOVA_HIP_CALL_LANES");
     const int v = e ? std::atoi(e) : 0;
