@@ -1534,6 +1534,28 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     rc = raytrace_impl(params, time, &color, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
                        denoise_available, denoise_available ? &albedo : nullptr, denoise_available ? &normal : nullptr, false);
     if (rc == 0) {
+      // the other lanes get their path state now rather than in the middle of a caller's loop (an allocation of
+      // ~1 GB waits for the device)
+      const uint32_t paths = g.fb.capacity;
+      const size_t spill = g.spill_words;
+      const int mine = g.cur;
+      for (int l = 0; l < L && rc == 0; l++) {
+        if (l == mine || (g.lanes[l].fb.capacity >= paths && g.lanes[l].spill_words >= spill)) continue;
+        switch_lane(l);
+        rc = ensure_frame_buffers(paths);
+        if (rc == 0 && g.spill_words < spill) { // the traversal stack beyond its LDS part (launch_traverse_wide)
+          (void) hipStreamSynchronize(g.stream);
+          (void) hipFree(g.d_spill);
+          g.d_spill = nullptr;
+          g.spill_words = 0;
+          hipError_t e = hipMalloc(&g.d_spill, spill * sizeof(uint32_t));
+          if (e == hipSuccess) g.spill_words = spill;
+          else rc = static_cast<int>(e);
+        }
+      }
+      switch_lane(mine);
+    }
+    if (rc == 0) {
       hipError_t e = hipStreamWaitEvent(g.stream, g.lane_mark[prev], 0);
       const int n_planes = denoise_available ? 3 : 1;
       float4* const dst[3] = { static_cast<float4*>(temp_color1->data),
