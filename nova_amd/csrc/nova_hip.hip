@@ -627,7 +627,7 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   const bool wide = cull && ((g.opt_kernel == 0 && !coherent) || g.opt_kernel == 6);
   const bool packet = cull && ((g.opt_kernel == 0 && coherent) || g.opt_kernel == 12);
   // ray-queue flags (traverse.hpp: TraverseArgs::flags).  Production = 0xD: sub-queues dealt to XCDs
-  // (mode 1), the three rays of a path next to each other, camera-ray kernel included — measured on
+  // (mode 1), the rays of a path next to each other, camera-ray kernel included — measured on
   // the 1080p frame: 3.79 -> 3.30 ms of traversal (each XCD's L2 then serves one part of the frame).
   // NOVA_HIP_OPT_TUNE bits 16+ override it for A/B runs (0x100 = all off).
   A.flags = (g.opt_tune >> 16) != 0 ? static_cast<uint32_t>(g.opt_tune >> 16) & 0xFFu : 0xDu;
