@@ -175,6 +175,7 @@ struct Ctx {
   int64_t opt_async = 1;
   int64_t opt_call_lanes = 0; // NOVA_HIP_OPT_CALL_LANES: 0 = built-in (kDefaultLanes, env NOVA_HIP_CALL_LANES)
   bool unsettled = false;
+  int samples_in_flight = 1; // lanes of the schedule the current launch belongs to (launch_traverse_wide)
   uint32_t* scratch_ptr = nullptr;       // device address of `scratch` on this device (hipGetSymbolAddress at init)
   bool no_alloc = false;                 // inside nova_hip_trace_rays_noalloc: no events, no buffer growth
   // options
@@ -564,7 +565,20 @@ constexpr int kWideBlocksPerCu = NOVA_P_MINWAVES; // = the resident work-groups 
 // k_traverse4: four-wide tree where the scene has one, hybrid LDS/global stack
 int launch_traverse_wide(const PackedScene& s, TraverseArgs A, bool count) {
   const uint32_t need = std::max(s.stack_need, s.stack_need_wide);
-  const unsigned per_cu = ((g.opt_tune >> 12) & 15) != 0 ? static_cast<unsigned>((g.opt_tune >> 12) & 15) : kWideBlocksPerCu; // A/B
+  // Work-groups per CU: 5 (every wave slot the kernel's registers allow) when the launch has the GPU to itself; fewer
+  // when kernels of several samples are in flight (lanes), so that they share every CU instead of queueing for it —
+  // 1080p frame, three lanes: 2.13 / 2.08 / 2.03 / 2.02 ms per sample with 5 / 4 / 3 / 2 (1 work-group: 2.41); the other
+  // configurations, four-call and fused: profiles/r03_blocks_per_cu_ab.txt.  The price is the end of a burst, where the
+  // last sample has the GPU to itself at reduced occupancy (profiles/r03_burst_length_ab.txt: 4 samples of the 4K room
+  // 9.4 / 9.7 / 10.2 ms with 5 / 3 / 2, 12 samples 9.27 / 9.14 / 9.37): 3 wins from 8 samples per burst on and loses
+  // least below.
+  static const unsigned shared_per_cu = [] {
+    const char* e = std::getenv("NOVA_HIP_SHARED_BLOCKS_PER_CU");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= 8 ? static_cast<unsigned>(v) : 3u;
+  }();
+  const unsigned per_cu = ((g.opt_tune >> 12) & 15) != 0 ? static_cast<unsigned>((g.opt_tune >> 12) & 15) // A/B
+                          : (g.samples_in_flight > 1 ? shared_per_cu : static_cast<unsigned>(kWideBlocksPerCu));
   const unsigned blocks = static_cast<unsigned>(g.num_cus) * per_cu;
   const size_t threads = static_cast<size_t>(blocks) * 256;
   const size_t words = need > static_cast<uint32_t>(kWideLdsStack) ? (need - kWideLdsStack) * threads : 0;
@@ -634,7 +648,8 @@ int launch_traverse(const PackedScene& s, TraverseArgs A, bool coherent) {
   if (packet) {
     // node and triangles through the scalar cache (the wave-uniform stack in registers instead of LDS made no
     // difference; nor did the same packet on the four-wide tree: profiles/r03_packet4_ab.txt)
-    const dim3 grid(static_cast<unsigned>(g.num_cus * 8)), block(256);
+    const unsigned packet_per_cu = ((g.opt_tune >> 24) & 15) != 0 ? static_cast<unsigned>((g.opt_tune >> 24) & 15) : 8u; // A/B
+    const dim3 grid(static_cast<unsigned>(g.num_cus) * packet_per_cu), block(256);
     if (count) hipLaunchKernelGGL((k_traverse_packet<true>), grid, block, 0, g.stream, A, A.nodes, A.tris);
     else hipLaunchKernelGGL((k_traverse_packet<false>), grid, block, 0, g.stream, A, A.nodes, A.tris);
     rc = static_cast<int>(hipGetLastError());
@@ -1519,12 +1534,16 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   const int L = (g.opt_async && g.opt_max_depth != 0 && images_ok && params && params->path_tracing &&
                  g.opt_tile_rank < g.opt_tile_ranks) ? want : 1;
   if (L > 1) {
+    const bool busy = g.unsettled;
     const size_t plane = static_cast<size_t>(width) * height * 16;
     rc = ensure_call_lanes(L, plane, denoise_available != 0);
     if (rc) return rc;
     const int prev = g.cur;
     HIP_TRY(hipEventRecord(g.lane_mark[prev], g.stream));
     switch_lane((prev + 1) % L);
+    // earlier calls still in flight: this sample will share the GPU with them.  A caller that reads the frame after every
+    // sample (Raytracer::raytrace does) finds the device idle here, and its sample gets the whole of every CU.
+    g.samples_in_flight = busy ? L : 1;
     nova_hip_image color = *temp_color1, albedo, normal;
     color.data = g.call_stage[g.cur][0];
     if (denoise_available) {
@@ -1533,6 +1552,7 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
     }
     rc = raytrace_impl(params, time, &color, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
                        denoise_available, denoise_available ? &albedo : nullptr, denoise_available ? &normal : nullptr, false);
+    g.samples_in_flight = 1;
     if (rc == 0) {
       // the other lanes get their path state now rather than in the middle of a caller's loop (an allocation of
       // ~1 GB waits for the device)
@@ -1843,6 +1863,7 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
     }
     return 0;
   };
+  g.samples_in_flight = static_cast<int>(L);
   // lane by lane: finish the sample that was started there L samples ago, start the next one
   for (uint32_t k = 0; k < num_samples && rc == 0; k++) {
     switch_lane(lane_of(k));
@@ -1853,6 +1874,7 @@ int nova_hip_render_samples(const nova_scene_params* params, const uint32_t* tim
     switch_lane(lane_of(k));
     rc = finish_sample(k);
   }
+  g.samples_in_flight = 1;
   if (rc) {
     wait_all();
     for (auto& pd : g_pending) pd.active = false;
