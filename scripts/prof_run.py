@@ -12,6 +12,9 @@ p = S.make_scene_params(cam, shading_metallic=0.4, shading_roughness=0.1)
 rt = Raytracer(0)
 rt.set_scene(sc, p, W, H)
 capi.set_option(capi.OPT_MAX_DEPTH, 5)
+# one sample at a time: rocprofv3's counter passes serialise dispatches anyway, and a launch that believes it shares the
+# GPU with other samples' kernels would run with 3 instead of 5 work-groups per CU (NOVA_HIP_OPT_CALL_LANES)
+capi.set_option(capi.OPT_CALL_LANES, 1)
 capi.set_option(capi.OPT_TRAVERSE_KERNEL, int(os.environ.get('NOVA_KERNEL', '0')))
 rt.start()
 for i in range(n):
