@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -219,6 +221,25 @@ struct Pending {
 };
 Pending g_pending[kMaxLanes];
 
+// Image work that waits for a sample whose paths are not all known to be dead (unbounded paths under lanes,
+// nova_hip_launch_raytrace).  With NOVA_HIP_OPT_MAX_DEPTH 0 a sample's first iterations are enqueued at once and the
+// survivor count is looked at when its lane comes round again — by then the answer is there without waiting, as in
+// nova_hip_render_samples.  Until then the calls that follow the launch in the caller's program (the copy of the
+// lane's planes into the caller's images, kernel_accumulate, copy_image2D, kernel_post_process) are kept here, in
+// program order, and run when the sample is finished: at the launch that reuses its lane, or when any other entry
+// point settles.  Each entry enqueues on its sample's lane; an event orders it behind the image work before it.
+struct Deferred {
+  uint64_t sample;
+  int lane;
+  std::function<int()> run;
+};
+std::deque<Deferred> g_deferred;
+uint64_t g_sample_seq = 0;      // the latest sample launched in this mode
+uint64_t g_sample_finished = 0; // the latest one whose remaining iterations have been enqueued
+int g_image_lane = -1;          // lane of the last image work enqueued in this mode (its lane_mark is recorded behind it)
+int g_issue_lane = 0;           // lane of the latest sample launched in this mode
+int (*g_flush_deferred)(uint64_t through_sample) = nullptr; // flush_deferred, once the mode has been used
+
 int require_ctx() {
   if (!g.ready) {
     int rc = nova_hip_init(0);
@@ -325,6 +346,15 @@ void collect_events() {
 int settle() {
   if (!g.ready || !g.unsettled) return 0;
   g.unsettled = false;
+  if (g_flush_deferred && !g_deferred.empty()) {
+    const int rc = g_flush_deferred(~0ull);
+    if (rc) {
+      g_deferred.clear();
+      (void) hipDeviceSynchronize();
+      collect_events();
+      return rc;
+    }
+  }
   HIP_TRY(hipStreamSynchronize(g.stream)); // the current lane holds the newest work, which waited for the others'
   for (int l = 0; l < g.lanes_ready; l++)
     if (l != g.cur && g.lanes[l].stream) HIP_TRY(hipStreamSynchronize(g.lanes[l].stream));
@@ -1132,13 +1162,20 @@ int nova_hip_image_write(nova_hip_image* image, const void* host_src) {
   return 0;
 }
 
+static int image_work(std::function<int()> run); // enqueue now, or behind a sample that is not whole yet (Deferred)
+
 int nova_hip_image_copy(nova_hip_image* dst, const nova_hip_image* src) {
   if (!dst || !src || !dst->data || !src->data || image_bytes(dst) != image_bytes(src))
     return NOVA_HIP_E_INVALID_ARGUMENT;
   int rc = require_ctx();
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(dst->data, src->data, image_bytes(dst), hipMemcpyDeviceToDevice, g.stream));
-  return launched();
+  void* const to = dst->data;
+  const void* const from = src->data;
+  const size_t bytes = image_bytes(dst);
+  return image_work([=]() -> int {
+    HIP_TRY(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, g.stream));
+    return 0;
+  });
 }
 
 int nova_hip_image_fill(nova_hip_image* image, const void* texel) {
@@ -1317,6 +1354,39 @@ static int raytrace_finish(Pending& pd) {
   return 0;
 }
 
+// Runs the kept image work of every sample up to `through_sample`, oldest first (see Deferred).
+static int flush_deferred(uint64_t through_sample) {
+  while (!g_deferred.empty() && g_deferred.front().sample <= through_sample) {
+    Deferred op = std::move(g_deferred.front());
+    g_deferred.pop_front();
+    switch_lane(op.lane);
+    if (op.sample != g_sample_finished) { // the first piece of work that needs this sample whole
+      g.samples_in_flight = g.lanes_ready;
+      const int rc = raytrace_finish(g_pending[op.lane]);
+      g.samples_in_flight = 1;
+      if (rc) return rc;
+      g_sample_finished = op.sample;
+    }
+    if (g_image_lane >= 0 && g_image_lane != op.lane) HIP_TRY(hipStreamWaitEvent(g.stream, g.lane_mark[g_image_lane], 0));
+    const int rc = op.run();
+    if (rc) return rc;
+    g.chain_tail = nullptr;
+    HIP_TRY(hipEventRecord(g.lane_mark[op.lane], g.stream));
+    g_image_lane = op.lane;
+  }
+  return 0;
+}
+// image work of the four-call schedule: now, or behind the sample it belongs to
+static int image_work(std::function<int()> run) {
+  if (g_deferred.empty()) {
+    const int rc = run();
+    return rc ? rc : launched();
+  }
+  g_deferred.push_back({ g_sample_seq, g_deferred.back().lane, std::move(run) });
+  g.unsettled = true;
+  return 0;
+}
+
 // the list of triangles with a light index for k_shade's pre-test, made once per contents of the meta buffer
 static int ensure_light_tris(const nova_triangle_meta* meta, const Alloc* am, const nova_triangle_data* tris, const Alloc* at,
                              uint32_t n_tris) {
@@ -1339,6 +1409,50 @@ static int ensure_light_tris(const nova_triangle_meta* meta, const Alloc* am, co
 }
 
 static int ensure_lanes(int lanes, size_t plane_bytes, bool features);
+// the current lane's own radiance planes into the caller's images (under a tile partition this rank's pixels only:
+// kernel_raytrace leaves the others as they are)
+static int copy_lane_planes(float4* const dst[3], int n_planes, uint32_t width, uint32_t height) {
+  const size_t plane = static_cast<size_t>(width) * height * 16;
+  if (g.opt_tile_ranks > 1) {
+    int rc = ensure_tile_plan(width, height);
+    if (rc) return rc;
+    const uint32_t n_pixels = width * height;
+    const unsigned blocks = std::min<unsigned>((n_pixels + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
+    for (int k = 0; k < n_planes; k++) {
+      hipLaunchKernelGGL(k_copy_kept, dim3(blocks), dim3(256), 0, g.stream, dst[k], g.call_stage[g.cur][k], g.plan.d_mask, n_pixels);
+      HIP_TRY(hipGetLastError());
+    }
+  } else {
+    for (int k = 0; k < n_planes; k++)
+      HIP_TRY(hipMemcpyAsync(dst[k], g.call_stage[g.cur][k], plane, hipMemcpyDeviceToDevice, g.stream));
+  }
+  g.chain_tail = nullptr;
+  return 0;
+}
+// every lane's path state and stack spill as large as the current lane's (an allocation of ~1 GB waits for the
+// device: better in the first call than in the middle of a caller's loop)
+static int size_other_lanes(int L) {
+  const uint32_t paths = g.fb.capacity;
+  const size_t spill = g.spill_words;
+  const int mine = g.cur;
+  int rc = 0;
+  for (int l = 0; l < L && rc == 0; l++) {
+    if (l == mine || (g.lanes[l].fb.capacity >= paths && g.lanes[l].spill_words >= spill)) continue;
+    switch_lane(l);
+    rc = ensure_frame_buffers(paths);
+    if (rc == 0 && g.spill_words < spill) { // the traversal stack beyond its LDS part (launch_traverse_wide)
+      (void) hipStreamSynchronize(g.stream);
+      (void) hipFree(g.d_spill);
+      g.d_spill = nullptr;
+      g.spill_words = 0;
+      hipError_t e = hipMalloc(&g.d_spill, spill * sizeof(uint32_t));
+      if (e == hipSuccess) g.spill_words = spill;
+      else rc = static_cast<int>(e);
+    }
+  }
+  switch_lane(mine);
+  return rc;
+}
 static int ensure_call_lanes(int lanes, size_t plane_bytes, bool features) {
   int rc = ensure_lanes(lanes, 0, false);
   if (rc) return rc;
@@ -1531,16 +1645,39 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
                          (!denoise_available || (float_image_ok(albedo_feature1, width, height) &&
                                                  float_image_ok(normal_feature1, width, height)));
   const int want = g.opt_call_lanes >= 1 ? static_cast<int>(g.opt_call_lanes) : env_lanes;
-  const int L = (g.opt_async && g.opt_max_depth != 0 && images_ok && params && params->path_tracing &&
-                 g.opt_tile_rank < g.opt_tile_ranks) ? want : 1;
+  const bool lanes_ok = g.opt_async && images_ok && params && params->path_tracing && g.opt_tile_rank < g.opt_tile_ranks;
+  const int L = lanes_ok ? want : 1;
+  const int n_planes = denoise_available ? 3 : 1;
+  if (!(L > 1 && g.opt_max_depth == 0) && !g_deferred.empty()) { // kept image work belongs in front of this launch
+    g.unsettled = true;
+    rc = settle();
+    if (rc) return rc;
+  }
   if (L > 1) {
     const bool busy = g.unsettled;
+    const bool unbounded = g.opt_max_depth == 0;
     const size_t plane = static_cast<size_t>(width) * height * 16;
     rc = ensure_call_lanes(L, plane, denoise_available != 0);
     if (rc) return rc;
-    const int prev = g.cur;
-    HIP_TRY(hipEventRecord(g.lane_mark[prev], g.stream));
-    switch_lane((prev + 1) % L);
+    int prev = g.cur, lane = (g.cur + 1) % L;
+    if (unbounded) {
+      // the sample that used the next lane last must be whole, and its image work enqueued, before the lane is reused
+      g_flush_deferred = &flush_deferred;
+      if (g_deferred.empty()) g_issue_lane = g.cur;
+      lane = (g_issue_lane + 1) % L;
+      if (g_sample_seq >= static_cast<uint64_t>(L)) {
+        rc = flush_deferred(g_sample_seq + 1 - static_cast<uint64_t>(L));
+        if (rc) {
+          g.unsettled = true;
+          (void) settle();
+          return rc;
+        }
+      }
+      prev = g.cur;
+    } else {
+      HIP_TRY(hipEventRecord(g.lane_mark[prev], g.stream));
+    }
+    switch_lane(lane);
     // earlier calls still in flight: this sample will share the GPU with them.  A caller that reads the frame after every
     // sample (Raytracer::raytrace does) finds the device idle here, and its sample gets the whole of every CU.
     g.samples_in_flight = busy ? L : 1;
@@ -1551,58 +1688,27 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
       normal = *normal_feature1; normal.data = g.call_stage[g.cur][2];
     }
     rc = raytrace_impl(params, time, &color, width, height, triangles, tri_meta, bvh, lights, num_lights, materials, sky,
-                       denoise_available, denoise_available ? &albedo : nullptr, denoise_available ? &normal : nullptr, false);
+                       denoise_available, denoise_available ? &albedo : nullptr, denoise_available ? &normal : nullptr, false,
+                       unbounded ? &g_pending[lane] : nullptr);
     g.samples_in_flight = 1;
-    if (rc == 0) {
-      // the other lanes get their path state now rather than in the middle of a caller's loop (an allocation of
-      // ~1 GB waits for the device)
-      const uint32_t paths = g.fb.capacity;
-      const size_t spill = g.spill_words;
-      const int mine = g.cur;
-      for (int l = 0; l < L && rc == 0; l++) {
-        if (l == mine || (g.lanes[l].fb.capacity >= paths && g.lanes[l].spill_words >= spill)) continue;
-        switch_lane(l);
-        rc = ensure_frame_buffers(paths);
-        if (rc == 0 && g.spill_words < spill) { // the traversal stack beyond its LDS part (launch_traverse_wide)
-          (void) hipStreamSynchronize(g.stream);
-          (void) hipFree(g.d_spill);
-          g.d_spill = nullptr;
-          g.spill_words = 0;
-          hipError_t e = hipMalloc(&g.d_spill, spill * sizeof(uint32_t));
-          if (e == hipSuccess) g.spill_words = spill;
-          else rc = static_cast<int>(e);
-        }
-      }
-      switch_lane(mine);
-    }
-    if (rc == 0) {
+    if (rc == 0) rc = size_other_lanes(L);
+    float4* const dst[3] = { static_cast<float4*>(temp_color1->data),
+                             denoise_available ? static_cast<float4*>(albedo_feature1->data) : nullptr,
+                             denoise_available ? static_cast<float4*>(normal_feature1->data) : nullptr };
+    if (rc == 0 && unbounded) {
+      // the copy into the caller's images, and every image call that follows, waits for the lane to come round (Deferred)
+      g_issue_lane = lane;
+      g_deferred.push_back({ ++g_sample_seq, lane, [=]() { return copy_lane_planes(dst, n_planes, width, height); } });
+    } else if (rc == 0) {
       hipError_t e = hipStreamWaitEvent(g.stream, g.lane_mark[prev], 0);
-      const int n_planes = denoise_available ? 3 : 1;
-      float4* const dst[3] = { static_cast<float4*>(temp_color1->data),
-                               denoise_available ? static_cast<float4*>(albedo_feature1->data) : nullptr,
-                               denoise_available ? static_cast<float4*>(normal_feature1->data) : nullptr };
-      if (g.opt_tile_ranks > 1) {
-        // kernel_raytrace writes this rank's pixels only; so does the copy
-        if (e == hipSuccess && ensure_tile_plan(width, height) != 0) e = hipErrorUnknown;
-        const uint32_t n_pixels = width * height;
-        const unsigned blocks = std::min<unsigned>((n_pixels + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
-        for (int k = 0; k < n_planes && e == hipSuccess; k++) {
-          hipLaunchKernelGGL(k_copy_kept, dim3(blocks), dim3(256), 0, g.stream, dst[k], g.call_stage[g.cur][k], g.plan.d_mask, n_pixels);
-          e = hipGetLastError();
-        }
-      } else {
-        for (int k = 0; k < n_planes && e == hipSuccess; k++)
-          e = hipMemcpyAsync(dst[k], g.call_stage[g.cur][k], plane, hipMemcpyDeviceToDevice, g.stream);
-      }
-      g.chain_tail = nullptr;
-      rc = static_cast<int>(e);
+      rc = e != hipSuccess ? static_cast<int>(e) : copy_lane_planes(dst, n_planes, width, height);
     }
     g.unsettled = true;
     if (rc) {
       (void) settle();
       return rc;
     }
-    return launched();
+    return unbounded ? 0 : launched();
   }
   rc = raytrace_impl(params, time, temp_color1, width, height, triangles, tri_meta, bvh, lights, num_lights,
                      materials, sky, denoise_available, albedo_feature1, normal_feature1, false);
@@ -1624,7 +1730,7 @@ static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
                            const nova_hip_image* prev_albedo_feature,
                            const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
                            nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
-                           uint32_t width, uint32_t height, bool sync) {
+                           uint32_t width, uint32_t height, bool sync, bool check_only = false) {
   int rc = require_ctx();
   if (rc) return rc;
   if (width == 0 || height == 0 || sample_index < 0) return NOVA_HIP_E_INVALID_ARGUMENT;
@@ -1660,6 +1766,7 @@ static int accumulate_impl(int32_t sample_index, uint32_t denoise_available,
     if (rc) return rc;
     A.mask = g.plan.d_mask;
   }
+  if (check_only) return 0;
   const unsigned blocks = std::min<unsigned>((width * height + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
   g.chain_tail = nullptr; // a later timing span must not start before this kernel
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, g.stream, A);
@@ -1675,10 +1782,17 @@ int nova_hip_launch_accumulate(int32_t sample_index, uint32_t denoise_available,
                                const nova_hip_image* prev_normal_feature, nova_hip_image* temp_color2,
                                nova_hip_image* albedo_feature2, nova_hip_image* normal_feature2,
                                uint32_t width, uint32_t height) {
-  int rc = accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
+  if (!g_deferred.empty()) { // behind a sample that is not whole yet: the arguments are checked now
+    const int rc = accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
+                                   prev_albedo_feature, prev_normal_feature, temp_color2, albedo_feature2, normal_feature2,
+                                   width, height, false, true);
+    if (rc) return rc;
+  }
+  return image_work([=]() {
+    return accumulate_impl(sample_index, denoise_available, temp_color1, albedo_feature1, normal_feature1, prev_color,
                            prev_albedo_feature, prev_normal_feature, temp_color2, albedo_feature2, normal_feature2,
                            width, height, false);
-  return rc ? rc : launched();
+  });
 }
 
 // ---- kernel_post_process -----------------------------------------------------------------------
@@ -1710,9 +1824,11 @@ int nova_hip_launch_post_process(const nova_scene_params* params, const nova_hip
   }
   const unsigned n = width * height;
   const unsigned blocks = std::min<unsigned>((n + 255) / 256, static_cast<unsigned>(g.num_cus) * 8u);
-  hipLaunchKernelGGL(k_post_process, dim3(blocks), dim3(256), 0, g.stream, A);
-  HIP_TRY(hipGetLastError());
-  return launched();
+  return image_work([=]() -> int {
+    hipLaunchKernelGGL(k_post_process, dim3(blocks), dim3(256), 0, g.stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  });
 }
 
 // ---- several samples in one call ---------------------------------------------------------------

@@ -19,10 +19,10 @@ def device():
     capi.set_option(capi.OPT_MAX_DEPTH, 0)
 
 
-def run(knot_small, mode, samples=5, w=200, h=136, lanes=0):
+def run(knot_small, mode, samples=5, w=200, h=136, lanes=0, depth=5):
     capi.set_option(capi.OPT_ASYNC_LAUNCH, mode)
     capi.set_option(capi.OPT_CALL_LANES, lanes)
-    capi.set_option(capi.OPT_MAX_DEPTH, 5)
+    capi.set_option(capi.OPT_MAX_DEPTH, depth)
     p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), shading_metallic=0.4, shading_roughness=0.1)
     rt = Raytracer(0, denoise_available=True)
     rt.set_scene(knot_small, p, w, h)
@@ -58,6 +58,58 @@ def test_lanes_in_turn_leave_the_images_of_one_lane(knot_small, lanes):
         assert (x == y).all()
     for name in ("rays_primary", "rays_bounce", "rays_shadow", "path_segments", "traverse_launches"):
         assert ka[name] == kb[name]
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_unbounded_paths_keep_their_image_work_until_the_lane_comes_round(knot_small, lanes):
+    """NOVA_HIP_OPT_MAX_DEPTH 0 (the reference's own rule): a sample's first iterations are enqueued at once, the
+    survivor count is looked at when its lane is reused, and kernel_accumulate / copy / post-process of the sample are
+    kept until then.  Eleven samples: every lane is reused several times and the burst ends with samples on every lane
+    still unfinished, which the first read has to finish in order."""
+    a, ka = run(knot_small, 1, samples=11, lanes=lanes, depth=0)
+    b, kb = run(knot_small, 0, samples=11, depth=0)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    for name in ("rays_primary", "rays_bounce", "rays_shadow", "path_segments"):
+        assert ka[name] == kb[name]
+    assert ka["traverse_launches"] >= 11 * 9  # paths longer than the eight iterations enqueued at once do occur
+
+
+def test_unbounded_paths_and_calls_that_interleave_other_work(knot_small):
+    """Reads, an option change and a second renderer between the samples of an unbounded burst."""
+    capi.set_option(capi.OPT_ASYNC_LAUNCH, 1)
+    capi.set_option(capi.OPT_CALL_LANES, 3)
+    capi.set_option(capi.OPT_MAX_DEPTH, 0)
+    w, h = 160, 96
+    p = S.make_scene_params(S.Camera(width=w, height=h, **S.DRAGON_CAMERA), shading_metallic=0.4, shading_roughness=0.1)
+    rt, other = Raytracer(0), Raytracer(0)
+    rt.set_scene(knot_small, p, w, h)
+    other.set_scene(knot_small, p, w, h)
+    rt.start()
+    other.start()
+    seen = []
+    for i in range(9):
+        rt.raytrace(50 + i, read_back=False)
+        if i % 2 == 0:
+            other.raytrace(90 + i, read_back=False)   # another set of images in the same program order
+        if i == 4:
+            seen.append(rt.temp_color_img2.read().view(np.uint32))  # a read in the middle settles what is kept
+        if i == 6:
+            capi.set_option(capi.OPT_CALL_LANES, 2)
+    got = [rt.temp_color_img2.read().view(np.uint32), other.temp_color_img2.read().view(np.uint32), rt.color_img.read()]
+    capi.set_option(capi.OPT_ASYNC_LAUNCH, 0)
+    rt.start()
+    other.start()
+    for i in range(9):
+        rt.raytrace(50 + i, read_back=False)
+        if i % 2 == 0:
+            other.raytrace(90 + i, read_back=False)
+        if i == 4:
+            seen.append(rt.temp_color_img2.read().view(np.uint32))
+    ref = [rt.temp_color_img2.read().view(np.uint32), other.temp_color_img2.read().view(np.uint32), rt.color_img.read()]
+    assert (seen[0] == seen[1]).all()
+    for x, y in zip(got, ref):
+        assert (x == y).all()
 
 
 def test_a_change_of_frame_size_between_calls(knot_small):
