@@ -401,9 +401,12 @@ enum {
                                    so that the kernel_raytrace of one sample runs beside the latency-bound tail and the
                                    image kernels of the sample before.  Each lane renders into planes of its own and
                                    copies them into temp_color1 / the feature images once every call made before it is
-                                   done with those images: the images hold what one lane would have left.  One lane
-                                   when paths are unbounded (NOVA_HIP_OPT_MAX_DEPTH 0).  Costs one set of path state
-                                   per extra lane (0.9 GB at 1080p) */
+                                   done with those images: the images hold what one lane would have left.  With
+                                   unbounded paths (NOVA_HIP_OPT_MAX_DEPTH 0) the library also keeps the image calls
+                                   that follow a launch (accumulate, copy, post-process) until the sample's lane comes
+                                   round, when it knows whether any path is still alive; they run in program order,
+                                   at the latest when another entry point waits.  Costs one set of path state per
+                                   extra lane (0.9 GB at 1080p) */
   NOVA_HIP_OPT_TUNE = 7         /* internal: bits 0-15 largest queue grab of a wave, in rays (0 = built-in);
                                    bits 16+ ray-queue flags for A/B runs (0 = production setting) */
 };

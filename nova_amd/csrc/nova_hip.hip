@@ -1634,8 +1634,8 @@ int nova_hip_launch_raytrace(const nova_scene_params* params, uint32_t time, nov
   // lane's stream with that lane's path state, beside the latency-bound tail and the image kernels of the call before.
   // It renders into the lane's own planes; those are copied into the caller's images once everything enqueued before
   // this call — which may still read the images — is done (under a tile partition only this rank's pixels: kernel_raytrace
-  // leaves the others of temp_color1 as they are).  One lane with unbounded paths (the host looks at the survivor count
-  // between iterations) and in blocking mode.
+  // leaves the others of temp_color1 as they are).  With unbounded paths the copy and the image calls that follow are
+  // kept until the lane comes round (Deferred).  One lane in blocking mode.
   static const int env_lanes = [] {
     const char* e = std::getenv("NOVA_HIP_CALL_LANES");
     const int v = e ? std::atoi(e) : 0;
