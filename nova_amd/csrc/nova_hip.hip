@@ -1010,6 +1010,9 @@ int nova_hip_shutdown(void) {
     for (auto& p : lane) (void) hipFree(p);
   for (hipEvent_t e : g.ev_pool) (void) hipEventDestroy(e);
   for (auto& pd : g_pending) pd = Pending {};
+  g_deferred.clear();
+  g_image_lane = -1; // its event went with the context
+  g_issue_lane = 0;
   // buffers from nova_hip_malloc belong to the caller and stay valid; the registry goes with them
   // ... and so do the options: they are per process (include/nova_hip.h), not per device context.  Counters
   // (rays, kernel times) are per context and start again at zero.

@@ -112,6 +112,16 @@ def test_unbounded_paths_and_calls_that_interleave_other_work(knot_small):
         assert (x == y).all()
 
 
+def test_shutdown_between_unbounded_bursts(knot_small):
+    """nova_hip_shutdown ends the context the lanes' events belong to; the next burst starts from nothing."""
+    a, _ = run(knot_small, 1, samples=5, lanes=3, depth=0)
+    capi.check(capi.load().nova_hip_shutdown())
+    capi.init(0)
+    b, _ = run(knot_small, 1, samples=5, lanes=3, depth=0)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+
+
 def test_a_change_of_frame_size_between_calls(knot_small):
     """The lanes' own planes grow with the frame; a smaller frame afterwards reuses them."""
     for w, h in ((96, 64), (200, 136), (64, 64)):
