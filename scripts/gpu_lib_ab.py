@@ -5,6 +5,11 @@ sys.path.insert(0, "/root/repo")
 from nova_amd import scene as S, capi
 from nova_amd.raytracer import Raytracer
 
+if os.environ.get("NOVA_AB_TORCH"):  # a process that also holds PyTorch's HIP runtime, streams and a tensor (bench.py --gpus N)
+    import torch
+    torch.cuda.set_device(0)
+    _keep = [torch.zeros(1 << 20, device="cuda"), torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
 capi.init(0)
 sc = S.dragon_standin()
 W, H = 1920, 1080
